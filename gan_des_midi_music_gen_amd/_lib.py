@@ -1,0 +1,72 @@
+"""ctypes binding of libgdm_hip.so (C ABI: include/gdm.h).  No fallback: a missing library is a hard error."""
+import ctypes
+import os
+import threading
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libgdm_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
+
+_c = ctypes
+_P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes); must list every function declared in include/gdm.h (tests/test_abi.py checks that)
+SIGNATURES = {
+    "gdm_last_error": (_c.c_char_p, []),
+    "gdm_version": (_I, []),
+    "gdm_arch": (_c.c_char_p, []),
+    "gdm_gemm": (_I, [_P, _I, _L, _L, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _I, _F, _I, _I, _P, _Z, _P]),
+    "gdm_bce_with_logits": (_I, [_P, _F, _I, _F, _P, _P, _I, _P]),
+    "gdm_adam_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _P]),
+    "gdm_bn_workspace_bytes": (_Z, [_I, _I]),
+    "gdm_bn_act_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P, _I, _P, _P, _I, _P, _Z, _P]),
+    "gdm_bn_act_bwd": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
+    "gdm_bias_act_fwd": (_I, [_P, _P, _I, _I, _I, _F, _P, _I, _P]),
+    "gdm_act_bwd": (_I, [_P, _P, _I, _L, _I, _F, _P, _P]),
+    "gdm_colsum": (_I, [_P, _I, _I, _I, _P, _P, _Z, _P]),
+    "gdm_cast": (_I, [_P, _I, _P, _I, _L, _P]),
+    "gdm_simnn_conv1_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "gdm_simnn_conv2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "gdm_simnn_conv2_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "gdm_simnn_conv2_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I]),
+    "gdm_simnn_conv2_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
+    "gdm_simnn_conv1_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I]),
+    "gdm_simnn_conv1_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
+    "gdm_im2col": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "gdm_col2im": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
+    "gdm_permute_pc": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class GdmError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if libgdm_hip.so has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise GdmError(
+                    f"{LIB_PATH} is missing: build it with `python -m gan_des_midi_music_gen_amd.build` "
+                    "(hipcc --offload-arch=gfx950). There is no CPU or eager-PyTorch fallback for this path.")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gdm_last_error().decode(errors="replace")
+        raise GdmError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,111 @@
+// Patch lowering for the small convolutions that run as GEMMs: model 2's DiscriminatorCNN (Conv2d k4 s2 p1,
+// MMGAN_MIDI_DES/network_tests.py:150-151) and model 1's generator (ConvTranspose2d, GAN_DES/SIMNN.py:70-81).
+//   im2col : cols[(b,oh,ow), (c,kh,kw)] = src[b, oh*s-p+kh, ow*s-p+kw, c]   (Conv2d forward and dW operand)
+//   col2im : dst[b,h,w,c] = sum_{kh,kw : (h+p-kh) % s == 0, ...} cols[(b,oh,ow),(c,kh,kw)]   (Conv2d dX and
+//            ConvTranspose2d forward), gather form: one lane per destination element, fixed summation order.
+// The k order (c, kh, kw) is torch's own weight order, so Conv2d weights (Cout, Cin*KH*KW) and ConvTranspose2d
+// weights (Cin, Cout*KH*KW) are used as GEMM operands in place, without a permuted copy.
+// Activations are channels-last, except the planar (NCHW fp32) piano-roll input / image output which is read or
+// written with its own index map.  gdm_permute_pc swaps the last two axes of a (B, P, C) array (NHWC <-> NCHW).
+#include "gdm_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ src, int sd, int planar, int B, int H,
+                                                     int W, int C, int KH, int KW, int stride, int pad, int OH, int OW,
+                                                     void* __restrict__ cols, int cd) {
+  const int K = KH * KW * C;
+  const int64_t total = (int64_t)B * OH * OW * K;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % K);
+    const int64_t row = i / K;
+    const int kw = k % KW, kh = (k / KW) % KH, c = k / (KW * KH);
+    const int ow = (int)(row % OW), oh = (int)((row / OW) % OH), b = (int)(row / ((int64_t)OW * OH));
+    const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+    float v = 0.f;
+    if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+      const int64_t si = planar ? (((int64_t)b * C + c) * H + ih) * W + iw : (((int64_t)b * H + ih) * W + iw) * C + c;
+      v = load_as_f32(src, sd, si);
+    }
+    store_from_f32(cols, cd, i, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void col2im_kernel(const void* __restrict__ cols, int cd, int B, int H, int W, int C,
+                                                     int KH, int KW, int stride, int pad, int OH, int OW,
+                                                     void* __restrict__ dst, int dd, int planar) {
+  const int K = KH * KW * C;
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int w = (int)((i / C) % W), h = (int)((i / ((int64_t)C * W)) % H), b = (int)(i / ((int64_t)C * W * H));
+    float s = 0.f;
+    for (int kh = 0; kh < KH; ++kh) {
+      const int th = h + pad - kh;
+      if (th < 0 || th % stride) continue;
+      const int oh = th / stride;
+      if (oh >= OH) continue;
+      for (int kw = 0; kw < KW; ++kw) {
+        const int tw = w + pad - kw;
+        if (tw < 0 || tw % stride) continue;
+        const int ow = tw / stride;
+        if (ow >= OW) continue;
+        s += load_as_f32(cols, cd, (((int64_t)b * OH + oh) * OW + ow) * K + (c * KH + kh) * KW + kw);
+      }
+    }
+    const int64_t di = planar ? (((int64_t)b * C + c) * H + h) * W + w : i;
+    store_from_f32(dst, dd, di, s);
+  }
+}
+
+// dst[b][c][p] = src[b][p][c]  (src viewed as (B, P, C)); used in both directions by swapping P and C
+__global__ __launch_bounds__(256) void permute_pc_kernel(const void* __restrict__ src, int dt, int B, int P, int C,
+                                                         void* __restrict__ dst) {
+  const int64_t total = (int64_t)B * P * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int p = (int)(i % P), c = (int)((i / P) % C), b = (int)(i / ((int64_t)P * C));
+    store_from_f32(dst, dt, i, load_as_f32(src, dt, ((int64_t)b * P + p) * C + c));
+  }
+}
+
+inline unsigned grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int gdm_im2col(const void* src, int src_dtype, int src_planar, int B, int H, int W, int C, int KH, int KW,
+                          int stride, int pad, int OH, int OW, void* cols, int cols_dtype, void* stream) {
+  GDM_REQUIRE(src && cols, "gdm_im2col: null pointer");
+  GDM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && OH > 0 && OW > 0,
+              "gdm_im2col: bad geometry");
+  GDM_REQUIRE(gdm_dtype_ok(src_dtype) && gdm_dtype_ok(cols_dtype), "gdm_im2col: bad dtype");
+  const int64_t total = (int64_t)B * OH * OW * KH * KW * C;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, src_dtype,
+                     src_planar, B, H, W, C, KH, KW, stride, pad, OH, OW, cols, cols_dtype);
+  GDM_LAUNCH_OK("gdm_im2col");
+  return GDM_OK;
+}
+
+extern "C" int gdm_col2im(const void* cols, int cols_dtype, int B, int H, int W, int C, int KH, int KW, int stride,
+                          int pad, int OH, int OW, void* dst, int dst_dtype, int dst_planar, void* stream) {
+  GDM_REQUIRE(cols && dst, "gdm_col2im: null pointer");
+  GDM_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && OH > 0 && OW > 0,
+              "gdm_col2im: bad geometry");
+  GDM_REQUIRE(gdm_dtype_ok(dst_dtype) && gdm_dtype_ok(cols_dtype), "gdm_col2im: bad dtype");
+  const int64_t total = (int64_t)B * H * W * C;
+  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, cols, cols_dtype, B, H,
+                     W, C, KH, KW, stride, pad, OH, OW, dst, dst_dtype, dst_planar);
+  GDM_LAUNCH_OK("gdm_col2im");
+  return GDM_OK;
+}
+
+extern "C" int gdm_permute_pc(const void* src, int dtype, int B, int P, int C, void* dst, void* stream) {
+  GDM_REQUIRE(src && dst && B > 0 && P > 0 && C > 0 && gdm_dtype_ok(dtype), "gdm_permute_pc: bad arguments");
+  const int64_t total = (int64_t)B * P * C;
+  hipLaunchKernelGGL(permute_pc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dtype, B, P, C,
+                     dst);
+  GDM_LAUNCH_OK("gdm_permute_pc");
+  return GDM_OK;
+}

@@ -1,0 +1,411 @@
+// Wavefront-level fused kernels around the GEMMs: BCE-with-logits (+ model 1's sigmoid chain), Adam, train-mode
+// batch norm + activation (forward/backward), bias+activation, column sums, casts.
+// All reductions are fixed-order (no float atomics) so a training run is bit-reproducible on one device.
+#include "gdm_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ BCE with logits
+// mean_i( max(x,0) - x*y + log1p(exp(-|x|)) ); nn.BCEWithLogitsLoss() at SIMNN.py:257 / network_tests.py:248.
+__global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ x, float target, int n, float gscale,
+                                                   float* __restrict__ loss, float* __restrict__ dx, int fuse_sig) {
+  __shared__ float red[1024];
+  const int t = threadIdx.x;
+  float s = 0.f;
+  for (int i = t; i < n; i += 1024) {
+    const float v = x[i];
+    s += fmaxf(v, 0.f) - v * target + log1pf(expf(-fabsf(v)));
+    if (dx) {
+      float g = (1.0f / (1.0f + expf(-v)) - target) * gscale / (float)n;
+      if (fuse_sig) g *= v * (1.f - v);   // v is itself sigmoid(z): chain to d/dz
+      dx[i] = g;
+    }
+  }
+  red[t] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (t < o) red[t] += red[t + o];
+    __syncthreads();
+  }
+  if (t == 0) loss[0] = red[0] / (float)n;
+}
+
+// ------------------------------------------------------------------------------------------------------------ Adam
+// torch.optim.Adam single-tensor update (lerp form of exp_avg, sqrt/bias-correction/eps order as torch).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float w1, float beta2, float one_minus_b2, float step_size,
+                                                   float bc2_sqrt, float eps) {
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 3 < n) {
+      f32x4 pp = *(const f32x4*)(p + i), gg = *(const f32x4*)(g + i), mm = *(const f32x4*)(m + i),
+            vv = *(const f32x4*)(v + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gj = gg[j];
+        const float mj = (w1 < 0.5f) ? mm[j] + w1 * (gj - mm[j]) : gj - (gj - mm[j]) * (1.f - w1);
+        const float vj = vv[j] * beta2 + one_minus_b2 * gj * gj;
+        const float denom = sqrtf(vj) / bc2_sqrt + eps;
+        pp[j] = pp[j] - step_size * (mj / denom);
+        mm[j] = mj;
+        vv[j] = vj;
+      }
+      *(f32x4*)(p + i) = pp;
+      *(f32x4*)(m + i) = mm;
+      *(f32x4*)(v + i) = vv;
+    } else {
+      for (int64_t k = i; k < n; ++k) {
+        const float gj = g[k];
+        const float mj = (w1 < 0.5f) ? m[k] + w1 * (gj - m[k]) : gj - (gj - m[k]) * (1.f - w1);
+        const float vj = v[k] * beta2 + one_minus_b2 * gj * gj;
+        const float denom = sqrtf(vj) / bc2_sqrt + eps;
+        p[k] = p[k] - step_size * (mj / denom);
+        m[k] = mj;
+        v[k] = vj;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- batch norm fwd
+// Stage 1: per (row-chunk, column) Welford triple (count, mean, M2); lanes = 64 consecutive columns, the 4 waves
+// of a workgroup interleave rows and are merged in wave order (Chan's formula).
+struct Welford { float n, mean, m2; };
+__device__ __forceinline__ void welford_add(Welford& a, float x) {
+  a.n += 1.f;
+  const float d = x - a.mean;
+  a.mean += d / a.n;
+  a.m2 += d * (x - a.mean);
+}
+__device__ __forceinline__ void welford_merge(Welford& a, const Welford& b) {
+  if (b.n == 0.f) return;
+  const float n = a.n + b.n;
+  const float d = b.mean - a.mean;
+  a.mean += d * (b.n / n);
+  a.m2 += b.m2 + d * d * (a.n * b.n / n);
+  a.n = n;
+}
+
+__global__ __launch_bounds__(256) void bn_partial_stats(const float* __restrict__ y, int rows, int C, int chunk_rows,
+                                                        float* __restrict__ ws) {
+  __shared__ Welford sh[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * chunk_rows, r1 = min(rows, r0 + chunk_rows);
+  Welford a{0.f, 0.f, 0.f};
+  if (c < C)
+    for (int r = r0 + wv; r < r1; r += 4) welford_add(a, y[(int64_t)r * C + c]);
+  sh[wv][lane] = a;
+  __syncthreads();
+  if (wv == 0 && c < C) {
+    Welford t = sh[0][lane];
+    welford_merge(t, sh[1][lane]);
+    welford_merge(t, sh[2][lane]);
+    welford_merge(t, sh[3][lane]);
+    float* o = ws + ((int64_t)blockIdx.y * C + c) * 3;
+    o[0] = t.n; o[1] = t.mean; o[2] = t.m2;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize(const float* __restrict__ ws, int chunks, int rows, int C,
+                                                   float momentum, float eps, float* __restrict__ running_mean,
+                                                   float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                   float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0 && nbt) nbt[0] += 1;
+  if (c >= C) return;
+  Welford t{0.f, 0.f, 0.f};
+  for (int k = 0; k < chunks; ++k) {
+    const float* o = ws + ((int64_t)k * C + c) * 3;
+    Welford b{o[0], o[1], o[2]};
+    welford_merge(t, b);
+  }
+  const float var_b = t.m2 / (float)rows;
+  save_mean[c] = t.mean;
+  save_invstd[c] = 1.0f / sqrtf(var_b + eps);
+  if (running_mean) {
+    const float var_u = t.m2 / (float)max(rows - 1, 1);
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * t.mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * var_u;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_eval_stats(const float* __restrict__ running_mean,
+                                                     const float* __restrict__ running_var, int C, float eps,
+                                                     float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  save_mean[c] = running_mean[c];
+  save_invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+__global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ y, int64_t total, int C,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                int act, void* __restrict__ out, int out_dtype) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    const float alpha = invstd[c] * gamma[c];
+    const float v = (y[i] - mean[c]) * alpha + beta[c];
+    store_from_f32(out, out_dtype, i, apply_act(v, act, 0.f));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- batch norm bwd
+// g = dout * act'(out); s1 = sum g, s2 = sum g*xhat (two-stage, fixed order); dy = gamma*invstd*(g - s1/R - xhat*s2/R)
+__global__ __launch_bounds__(256) void bn_bwd_partial(const void* __restrict__ dout, const void* __restrict__ out,
+                                                      int dtype, const float* __restrict__ y, int rows, int C,
+                                                      int chunk_rows, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, int act,
+                                                      float* __restrict__ ws) {
+  __shared__ float sh1[4][64], sh2[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * chunk_rows, r1 = min(rows, r0 + chunk_rows);
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const float mu = mean[c], is = invstd[c];
+    for (int r = r0 + wv; r < r1; r += 4) {
+      const int64_t i = (int64_t)r * C + c;
+      const float g = load_as_f32(dout, dtype, i) * act_grad_from_out(load_as_f32(out, dtype, i), act, 0.f);
+      s1 += g;
+      s2 += g * ((y[i] - mu) * is);
+    }
+  }
+  sh1[wv][lane] = s1; sh2[wv][lane] = s2;
+  __syncthreads();
+  if (wv == 0 && c < C) {
+    float* o = ws + ((int64_t)blockIdx.y * C + c) * 2;
+    o[0] = ((sh1[0][lane] + sh1[1][lane]) + sh1[2][lane]) + sh1[3][lane];
+    o[1] = ((sh2[0][lane] + sh2[1][lane]) + sh2[2][lane]) + sh2[3][lane];
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize(const float* __restrict__ ws, int chunks, int C,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < chunks; ++k) {
+    s1 += ws[((int64_t)k * C + c) * 2];
+    s2 += ws[((int64_t)k * C + c) * 2 + 1];
+  }
+  dbeta[c] = s1;
+  dgamma[c] = s2;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply(const void* __restrict__ dout, const void* __restrict__ out,
+                                                    int dtype, const float* __restrict__ y, int64_t total, int rows,
+                                                    int C, const float* __restrict__ gamma,
+                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                    int act, float* __restrict__ dy) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const float inv_r = 1.0f / (float)rows;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    const float g = load_as_f32(dout, dtype, i) * act_grad_from_out(load_as_f32(out, dtype, i), act, 0.f);
+    const float xhat = (y[i] - mean[c]) * invstd[c];
+    dy[i] = gamma[c] * invstd[c] * (g - dbeta[c] * inv_r - xhat * dgamma[c] * inv_r);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ small pointwise
+__global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                       int64_t total, int cols, int act, float slope,
+                                                       void* __restrict__ out, int out_dtype) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    float v = x[i];
+    if (bias) v += bias[i % cols];
+    store_from_f32(out, out_dtype, i, apply_act(v, act, slope));
+  }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ out,
+                                                      int dtype, int64_t n, int act, float slope,
+                                                      void* __restrict__ dx) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float g = load_as_f32(dout, dtype, i) * act_grad_from_out(load_as_f32(out, dtype, i), act, slope);
+    store_from_f32(dx, dtype, i, g);
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_partial(const void* __restrict__ x, int dtype, int rows, int C,
+                                                      int chunk_rows, float* __restrict__ ws) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * chunk_rows, r1 = min(rows, r0 + chunk_rows);
+  float s = 0.f;
+  if (c < C)
+    for (int r = r0 + wv; r < r1; r += 4) s += load_as_f32(x, dtype, (int64_t)r * C + c);
+  sh[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && c < C) ws[(int64_t)blockIdx.y * C + c] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+}
+
+__global__ __launch_bounds__(256) void colsum_final(const float* __restrict__ ws, int chunks, int C,
+                                                    float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += ws[(int64_t)k * C + c];
+  out[c] = s;
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const void* __restrict__ src, int sd, void* __restrict__ dst,
+                                                   int dd, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+    store_from_f32(dst, dd, i, load_as_f32(src, sd, i));
+}
+
+inline int row_chunks(int rows) {
+  int c = (rows + 63) / 64;          // >= 64 rows per chunk (16 per wave)
+  return c < 1 ? 1 : (c > 256 ? 256 : c);
+}
+inline unsigned grid_for(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int gdm_bce_with_logits(const float* x, float target, int n, float grad_scale, float* loss, float* dx,
+                                   int fuse_sigmoid_backward, void* stream) {
+  GDM_REQUIRE(x && loss, "gdm_bce_with_logits: null pointer");
+  GDM_REQUIRE(n > 0 && n <= 65536, "gdm_bce_with_logits: n=%d out of range (1..65536)", n);
+  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, target, n, grad_scale, loss, dx,
+                     fuse_sigmoid_backward);
+  GDM_LAUNCH_OK("gdm_bce_with_logits");
+  return GDM_OK;
+}
+
+extern "C" int gdm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
+                             float beta2, float eps, void* stream) {
+  GDM_REQUIRE(p && g && m && v, "gdm_adam_step: null pointer");
+  GDM_REQUIRE(n > 0 && step >= 1, "gdm_adam_step: bad n=%lld or step=%d", (long long)n, step);
+  GDM_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+              "gdm_adam_step: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                     1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2_sqrt, eps);
+  GDM_LAUNCH_OK("gdm_adam_step");
+  return GDM_OK;
+}
+
+extern "C" size_t gdm_bn_workspace_bytes(int rows, int channels) {
+  return (size_t)row_chunks(rows) * (size_t)channels * 3 * sizeof(float);
+}
+
+extern "C" int gdm_bn_act_fwd(const float* y, int rows, int channels, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                              float eps, int act, void* out, int out_dtype, float* save_mean, float* save_invstd,
+                              int training, void* workspace, size_t workspace_bytes, void* stream) {
+  GDM_REQUIRE(y && gamma && beta && out && save_mean && save_invstd, "gdm_bn_act_fwd: null pointer");
+  GDM_REQUIRE(rows > 0 && channels > 0 && gdm_dtype_ok(out_dtype), "gdm_bn_act_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int C = channels;
+  if (training) {
+    GDM_REQUIRE(rows > 1, "gdm_bn_act_fwd: training-mode batch norm needs more than 1 value per channel");
+    const int chunks = row_chunks(rows);
+    if (!workspace || workspace_bytes < gdm_bn_workspace_bytes(rows, C)) {
+      gdm_set_error("gdm_bn_act_fwd: workspace too small");
+      return GDM_EWORKSPACE;
+    }
+    const int chunk_rows = (rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(bn_partial_stats, dim3((C + 63) / 64, chunks), dim3(256), 0, s, y, rows, C, chunk_rows,
+                       (float*)workspace);
+    hipLaunchKernelGGL(bn_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, chunks, rows, C,
+                       momentum, eps, running_mean, running_var, num_batches_tracked, save_mean, save_invstd);
+  } else {
+    GDM_REQUIRE(running_mean && running_var, "gdm_bn_act_fwd: eval mode needs running statistics");
+    hipLaunchKernelGGL(bn_eval_stats, dim3((C + 255) / 256), dim3(256), 0, s, running_mean, running_var, C, eps,
+                       save_mean, save_invstd);
+  }
+  const int64_t total = (int64_t)rows * C;
+  hipLaunchKernelGGL(bn_apply, dim3(grid_for(total)), dim3(256), 0, s, y, total, C, gamma, beta, save_mean,
+                     save_invstd, act, out, out_dtype);
+  GDM_LAUNCH_OK("gdm_bn_act_fwd");
+  return GDM_OK;
+}
+
+extern "C" int gdm_bn_act_bwd(const void* dout, const void* out, int out_dtype, const float* y, int rows, int channels,
+                              const float* gamma, const float* save_mean, const float* save_invstd, int act,
+                              float* dy, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  GDM_REQUIRE(dout && out && y && gamma && save_mean && save_invstd && dy && dgamma && dbeta,
+              "gdm_bn_act_bwd: null pointer");
+  GDM_REQUIRE(rows > 0 && channels > 0 && gdm_dtype_ok(out_dtype), "gdm_bn_act_bwd: bad arguments");
+  const int C = channels, chunks = row_chunks(rows);
+  if (!workspace || workspace_bytes < gdm_bn_workspace_bytes(rows, C)) {
+    gdm_set_error("gdm_bn_act_bwd: workspace too small");
+    return GDM_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int chunk_rows = (rows + chunks - 1) / chunks;
+  hipLaunchKernelGGL(bn_bwd_partial, dim3((C + 63) / 64, chunks), dim3(256), 0, s, dout, out, out_dtype, y, rows, C,
+                     chunk_rows, save_mean, save_invstd, act, (float*)workspace);
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, chunks, C,
+                     dgamma, dbeta);
+  const int64_t total = (int64_t)rows * C;
+  hipLaunchKernelGGL(bn_bwd_apply, dim3(grid_for(total)), dim3(256), 0, s, dout, out, out_dtype, y, total, rows, C,
+                     gamma, save_mean, save_invstd, dgamma, dbeta, act, dy);
+  GDM_LAUNCH_OK("gdm_bn_act_bwd");
+  return GDM_OK;
+}
+
+extern "C" int gdm_bias_act_fwd(const float* x, const float* bias, int rows, int cols, int act, float slope, void* out,
+                                int out_dtype, void* stream) {
+  GDM_REQUIRE(x && out && rows > 0 && cols > 0 && gdm_dtype_ok(out_dtype), "gdm_bias_act_fwd: bad arguments");
+  const int64_t total = (int64_t)rows * cols;
+  hipLaunchKernelGGL(bias_act_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, bias, total, cols,
+                     act, slope, out, out_dtype);
+  GDM_LAUNCH_OK("gdm_bias_act_fwd");
+  return GDM_OK;
+}
+
+extern "C" int gdm_act_bwd(const void* dout, const void* out, int dtype, int64_t n, int act, float slope, void* dx,
+                           void* stream) {
+  GDM_REQUIRE(dout && out && dx && n > 0 && gdm_dtype_ok(dtype), "gdm_act_bwd: bad arguments");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dout, out, dtype, n, act,
+                     slope, dx);
+  GDM_LAUNCH_OK("gdm_act_bwd");
+  return GDM_OK;
+}
+
+extern "C" int gdm_colsum(const void* x, int dtype, int rows, int cols, float* out, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  GDM_REQUIRE(x && out && rows > 0 && cols > 0 && gdm_dtype_ok(dtype), "gdm_colsum: bad arguments");
+  const int chunks = row_chunks(rows);
+  if (!workspace || workspace_bytes < (size_t)chunks * cols * sizeof(float)) {
+    gdm_set_error("gdm_colsum: workspace too small (need %zu)", (size_t)chunks * cols * sizeof(float));
+    return GDM_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int chunk_rows = (rows + chunks - 1) / chunks;
+  hipLaunchKernelGGL(colsum_partial, dim3((cols + 63) / 64, chunks), dim3(256), 0, s, x, dtype, rows, cols, chunk_rows,
+                     (float*)workspace);
+  hipLaunchKernelGGL(colsum_final, dim3((cols + 255) / 256), dim3(256), 0, s, (const float*)workspace, chunks, cols,
+                     out);
+  GDM_LAUNCH_OK("gdm_colsum");
+  return GDM_OK;
+}
+
+extern "C" int gdm_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream) {
+  GDM_REQUIRE(src && dst && n > 0 && gdm_dtype_ok(src_dtype) && gdm_dtype_ok(dst_dtype), "gdm_cast: bad arguments");
+  hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, src_dtype, dst,
+                     dst_dtype, n);
+  GDM_LAUNCH_OK("gdm_cast");
+  return GDM_OK;
+}

@@ -1,0 +1,728 @@
+// Convolution trunk of model 1's discriminator (GAN_DES/SIMNN.py:123-125, 136-139) for gfx950.
+//
+//   x (B,H,W) fp32 --conv1 k2 p1 +ReLU +pool2--> p1 (B,H1,W1,16) channels-last
+//                  --conv2 k3 p1 +ReLU +pool2--> p2 (B,32,H2,W2) channel-major (= the reference's flatten order)
+//
+// conv1 (K = 4) is an HBM-bound stencil: one lane per pooled pixel, all 16 channels in registers.
+// conv2 (K = 144) is an implicit GEMM on MFMA with M = output channels, N = 16 consecutive pixels of a row,
+// the input halo band staged once in LDS as [row][col][channel]; ReLU, the 2x2 max-pool and its argmax code are
+// applied to the accumulator tile (row pair in two accumulators, column pair by a lane swap) before anything is
+// written, so the full-resolution conv outputs never touch HBM.  Backward kernels rebuild the sparse full-resolution
+// gradient (one non-zero per pooling window) in LDS from the pooled gradient + the 1-byte code.
+//
+// T = float : exact-fp32 mode, v_mfma_f32_16x16x4_f32, LDS pixel records padded to avoid bank conflicts
+// T = __bf16: bf16 storage + v_mfma_f32_16x16x32_bf16, fp32 accumulation
+#include "gdm_common.h"
+
+namespace {
+
+constexpr int COLS = 128;  // conv-output columns handled per workgroup (column super-tile)
+
+template <typename T> struct Px;  // LDS pixel-record strides (elements) for 16- and 32-channel records
+template <> struct Px<float> { static constexpr int S16 = 17, S32 = 33; };
+template <> struct Px<__bf16> { static constexpr int S16 = 16, S32 = 32; };
+
+// =====================================================================================================================
+// conv1 forward: Conv2d(1,16,k2,s1,p1) + ReLU + MaxPool2d(2)
+// code1 (uint64 per pooled pixel): bits [2c+1:2c] = argmax position (dy*2+dx, first max in scan order like
+// aten::max_pool2d_with_indices), bit 32+c = channel c is live (pooled value > 0, i.e. ReLU passes gradient).
+// =====================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int B, int H, int W, int H1,
+                                                        int W1, T* __restrict__ p1, uint64_t* __restrict__ code1) {
+  const int64_t total = (int64_t)B * H1 * W1;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int pw = (int)(idx % W1);
+    const int ph = (int)((idx / W1) % H1);
+    const int b = (int)(idx / ((int64_t)W1 * H1));
+    const float* xb = x + (int64_t)b * H * W;
+    float in[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int ih = 2 * ph - 1 + r;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int iw = 2 * pw - 1 + s;
+        in[r][s] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? xb[(int64_t)ih * W + iw] : 0.f;
+      }
+    }
+    uint64_t code = 0;
+    T outv[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float w00 = w[c * 4 + 0], w01 = w[c * 4 + 1], w10 = w[c * 4 + 2], w11 = w[c * 4 + 3], bc = bias[c];
+      float best = 0.f;
+      int bi = 0;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          // same accumulation order as a k-ordered dot product: ((b + w00*x00) + w01*x01) + ...
+          float v = in[dy][dx] * w00;
+          v = fmaf(in[dy][dx + 1], w01, v);
+          v = fmaf(in[dy + 1][dx], w10, v);
+          v = fmaf(in[dy + 1][dx + 1], w11, v);
+          v += bc;
+          v = v > 0.f ? v : 0.f;
+          if ((dy == 0 && dx == 0) || v > best) { best = v; bi = dy * 2 + dx; }
+        }
+      outv[c] = from_f32<T>(best);
+      code |= (uint64_t)bi << (2 * c);
+      if (best > 0.f) code |= 1ull << (32 + c);
+    }
+    T* o = p1 + idx * 16;
+    if constexpr (sizeof(T) == 2) {
+      *(bf16x8*)(o) = *(bf16x8*)&outv[0];
+      *(bf16x8*)(o + 8) = *(bf16x8*)&outv[8];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(f32x4*)(o + 4 * q) = *(f32x4*)&outv[4 * q];
+    }
+    code1[idx] = code;
+  }
+}
+
+// =====================================================================================================================
+// conv1 backward (weights): dW1[c][kh][kw] = sum live * dp1[c] * x[2ph+dy-1+kh][2pw+dx-1+kw], db1[c] = sum live*dp1[c]
+// Two-stage fixed-order reduction: per-workgroup slab of 80 floats, then a 1-block final sum.
+// =====================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restrict__ dp1,
+                                                               const uint64_t* __restrict__ code1,
+                                                               const float* __restrict__ x, int B, int H, int W,
+                                                               int H1, int W1, float* __restrict__ slabs) {
+  __shared__ float red[4][80];
+  float acc[80];
+#pragma unroll
+  for (int i = 0; i < 80; ++i) acc[i] = 0.f;
+  const int64_t total = (int64_t)B * H1 * W1;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int pw = (int)(idx % W1);
+    const int ph = (int)((idx / W1) % H1);
+    const int b = (int)(idx / ((int64_t)W1 * H1));
+    const float* xb = x + (int64_t)b * H * W;
+    float in[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int ih = 2 * ph - 1 + r;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int iw = 2 * pw - 1 + s;
+        in[r][s] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? xb[(int64_t)ih * W + iw] : 0.f;
+      }
+    }
+    const uint64_t code = code1[idx];
+    const T* g16 = dp1 + idx * 16;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const bool live = (code >> (32 + c)) & 1;
+      const float g = live ? to_f32(g16[c]) : 0.f;
+      const int pos = (int)((code >> (2 * c)) & 3);
+      const bool dy = pos >> 1, dx = pos & 1;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 2; ++kw) {
+          const float a = dx ? in[kh][kw + 1] : in[kh][kw];
+          const float bsel = dx ? in[kh + 1][kw + 1] : in[kh + 1][kw];
+          acc[c * 4 + kh * 2 + kw] = fmaf(g, dy ? bsel : a, acc[c * 4 + kh * 2 + kw]);
+        }
+      acc[64 + c] += g;
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 80; ++i) {
+    const float s = wave_sum(acc[i]);
+    if (lane == 0) red[wv][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 80)
+    slabs[(int64_t)blockIdx.x * 80 + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(128) void conv1_bwd_weight_final(const float* __restrict__ slabs, int nslabs,
+                                                              float* __restrict__ dw, float* __restrict__ db) {
+  const int i = threadIdx.x;
+  if (i >= 80) return;
+  float s = 0.f;
+  for (int k = 0; k < nslabs; ++k) s += slabs[(int64_t)k * 80 + i];
+  if (i < 64) dw[i] = s; else db[i - 64] = s;
+}
+
+// =====================================================================================================================
+// conv2 forward: Conv2d(16,32,k3,s1,p1) + ReLU + MaxPool2d(2), implicit GEMM.
+// Workgroup = (column super-tile, pooled row ph, image b): conv rows 2ph, 2ph+1, conv cols [c0, c0+128).
+// LDS: in_s[4][COLS+2][S16] (rows 2ph-1..2ph+2, cols c0-1..c0+128), w_s[32][KP] with k = tap*16 + ci.
+// Wave w owns conv cols [c0+32w, c0+32w+32): accumulators acc[mtile 2][dy 2][jx 2].
+// code2 byte: 0..3 argmax position (dy*2+dx), 4 = dead (pooled value is 0 after ReLU).
+// =====================================================================================================================
+template <typename T> struct C2 {
+  static constexpr int KP = sizeof(T) == 2 ? 168 : 146;  // weight row stride (elements); bf16 rows hold 160 k (padded)
+  static constexpr int S16 = Px<T>::S16;
+  static constexpr int IN_ELEMS = 4 * (COLS + 2) * S16;
+  static constexpr int W_ELEMS = 32 * KP;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int H1, int W1, int H2,
+                                                        int W2, T* __restrict__ p2, uint8_t* __restrict__ code2) {
+  constexpr int S16 = C2<T>::S16, KP = C2<T>::KP, WP = COLS + 2;
+  __shared__ __attribute__((aligned(16))) T smem[C2<T>::IN_ELEMS + C2<T>::W_ELEMS];
+  T* in_s = smem;
+  T* w_s = smem + C2<T>::IN_ELEMS;
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
+  const int c0 = blockIdx.x * COLS, ph = blockIdx.y, b = blockIdx.z;
+
+  // ---- stage weights: w (32,16,3,3) -> w_s[o][tap*16+ci]
+  for (int i = t; i < 32 * (KP); i += 256) {
+    const int o = i / KP, k = i % KP;
+    float v = 0.f;
+    if (k < 144) { const int tap = k >> 4, ci = k & 15; v = w[(o * 16 + ci) * 9 + tap]; }
+    w_s[i] = from_f32<T>(v);
+  }
+  // ---- stage input band (channels-last records; 16-B pieces, zero outside the image)
+  {
+    constexpr int PIECES = (sizeof(T) == 2) ? 2 : 4;   // 16-byte pieces per pixel record
+    constexpr int EPP = 16 / PIECES;                     // elements per piece
+    const T* src = p1 + (int64_t)b * H1 * W1 * 16;
+    for (int i = t; i < 4 * WP * PIECES; i += 256) {
+      const int piece = i % PIECES, pix = i / PIECES;
+      const int cl = pix % WP, rl = pix / WP;
+      const int r = 2 * ph - 1 + rl, c = c0 - 1 + cl;
+      T* dst = in_s + (rl * WP + cl) * S16 + piece * EPP;
+      if (r >= 0 && r < H1 && c >= 0 && c < W1) {
+        const T* s = src + ((int64_t)r * W1 + c) * 16 + piece * EPP;
+        if constexpr (sizeof(T) == 2) *(bf16x8*)dst = *(const bf16x8*)s;
+        else { const f32x4 v = *(const f32x4*)s; dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPP; ++e) dst[e] = from_f32<T>(0.f);
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[2][2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][d][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int colb = 32 * wv + lr;  // local conv column of this lane for jx = 0
+
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      int tap = 2 * ks + (lg >> 1);
+      tap = tap > 8 ? 8 : tap;               // k >= 144: weights are zero, read any valid record
+      const int kh = tap / 3, kw = tap % 3;
+      bf16x8 a[2], bb[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8*)&w_s[(16 * i + lr) * KP + 32 * ks + 8 * lg];
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bb[d][j] = *(const bf16x8*)&in_s[((d + kh) * WP + colb + 16 * j + kw) * S16 + 8 * (lg & 1)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][d][j] = mfma16(a[i], bb[d][j], acc[i][d][j]);
+    }
+  } else {
+#pragma unroll 4
+    for (int ks = 0; ks < 36; ++ks) {
+      const int tap = ks >> 2, ci = 4 * (ks & 3) + lg;
+      const int kh = tap / 3, kw = tap % 3;
+      float a[2], bb[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = w_s[(16 * i + lr) * KP + 4 * ks + lg];
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bb[d][j] = in_s[((d + kh) * WP + colb + 16 * j + kw) * S16 + ci];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][d][j] = mfma16(a[i], bb[d][j], acc[i][d][j]);
+    }
+  }
+  __syncthreads();  // in_s is dead from here: reuse it for the pooled output tile
+
+  // ---- epilogue: bias, ReLU, 2x2 max-pool (+code) -> out_s[32][64] / code_s[32][64] -> coalesced channel-major store
+  T* out_s = smem;                                  // 32*64 elements
+  uint8_t* code_s = (uint8_t*)(smem + 32 * 64);     // 32*64 bytes
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 16 * i + 4 * lg + r;
+        const float bo = bias[o];
+        float v0 = acc[i][0][j][r] + bo, v1 = acc[i][1][j][r] + bo;
+        v0 = v0 > 0.f ? v0 : 0.f;
+        v1 = v1 > 0.f ? v1 : 0.f;
+        const float u0 = __shfl_xor(v0, 1, 64), u1 = __shfl_xor(v1, 1, 64);
+        if ((lr & 1) == 0) {
+          float best = v0; int bi = 0;
+          if (u0 > best) { best = u0; bi = 1; }
+          if (v1 > best) { best = v1; bi = 2; }
+          if (u1 > best) { best = u1; bi = 3; }
+          const int pwl = (32 * wv + 16 * j + lr) >> 1;
+          out_s[o * 64 + pwl] = from_f32<T>(best);
+          code_s[o * 64 + pwl] = best > 0.f ? (uint8_t)bi : (uint8_t)4;
+        }
+      }
+  __syncthreads();
+  {
+    const int pwl = t & 63;
+    const int pw = (c0 >> 1) + pwl;
+    if (pw < W2) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int o = (t >> 6) + 4 * q;
+        const int64_t gi = (((int64_t)b * 32 + o) * H2 + ph) * W2 + pw;
+        p2[gi] = out_s[o * 64 + pwl];
+        code2[gi] = code_s[o * 64 + pwl];
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
+// Shared by both conv2 backward kernels: rebuild rows [r_first, r_first+NR) x cols [cfirst, cfirst+NC) of the sparse
+// full-resolution gradient dc2[r][c][o] = (code2[o][r/2][c/2] == 2*(r&1)+(c&1)) ? dp2[o][r/2][c/2] : 0 in LDS as
+// [row][col][S32] records.  Each work item = (pooled row, pooled col, group of 8 channels); a lane keeps its
+// channel group (t & 3) so that it can also accumulate the bias gradient (sum of live dp2) in `bsum`.
+// =====================================================================================================================
+template <typename T, int NR, int NC, bool WITH_BSUM>
+__device__ __forceinline__ void stage_dc2(const T* __restrict__ dp2b, const uint8_t* __restrict__ code2b, int H2,
+                                          int W2, int r_first, int c_first, T* __restrict__ dc_s, float* bsum) {
+  constexpr int S32 = Px<T>::S32;
+  const int t = threadIdx.x;
+  const int og = t & 3;                                   // channels 8*og .. 8*og+7
+  const int pr_first = r_first >> 1;                      // arithmetic shift: floor for negatives
+  const int pc_first = c_first >> 1;
+  const int npr = ((r_first + NR - 1) >> 1) - pr_first + 1;
+  const int npc = ((c_first + NC - 1) >> 1) - pc_first + 1;
+  for (int it = t >> 2; it < npr * npc; it += 64) {
+    const int pcl = it % npc, prl = it / npc;
+    const int pr = pr_first + prl, pc = pc_first + pcl;
+    const bool valid = pr >= 0 && pr < H2 && pc >= 0 && pc < W2;
+    float g[8];
+    int cd[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      g[e] = 0.f; cd[e] = 4;
+      if (valid) {
+        const int64_t gi = ((int64_t)(8 * og + e) * H2 + pr) * W2 + pc;
+        g[e] = to_f32(dp2b[gi]);
+        cd[e] = code2b[gi];
+        if (WITH_BSUM) bsum[e] += (cd[e] < 4) ? g[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+      const int rl = 2 * pr + (pos >> 1) - r_first, cl = 2 * pc + (pos & 1) - c_first;
+      if (rl >= 0 && rl < NR && cl >= 0 && cl < NC) {
+        T* dst = dc_s + (rl * NC + cl) * S32 + 8 * og;
+        if constexpr (sizeof(T) == 2) {
+          bf16x8 v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (__bf16)(cd[e] == pos ? g[e] : 0.f);
+          *(bf16x8*)dst = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dst[e] = cd[e] == pos ? g[e] : 0.f;
+        }
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
+// conv2 backward (data): dp1[ih][iw][ci] = sum_{ah,aw,o} dc2[ih-1+ah][iw-1+aw][o] * w[o][ci][2-ah][2-aw]
+// Same tiling as the forward with CIN=32 (K = 288), M = 16 input channels; output written channels-last.
+// =====================================================================================================================
+template <typename T> struct D2 {
+  static constexpr int KP = sizeof(T) == 2 ? 296 : 290;   // 288 k + pad (bf16: 16-B aligned rows; f32: stride/2 odd)
+  static constexpr int S32 = Px<T>::S32;
+  static constexpr int DC_ELEMS = 4 * (COLS + 2) * S32;
+  static constexpr int W_ELEMS = 16 * KP;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict__ dp2,
+                                                             const uint8_t* __restrict__ code2,
+                                                             const float* __restrict__ w, int H1, int W1, int H2,
+                                                             int W2, T* __restrict__ dp1) {
+  constexpr int S32 = D2<T>::S32, KP = D2<T>::KP, WP = COLS + 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  T* dc_s = (T*)dyn_smem;
+  T* w_s = dc_s + D2<T>::DC_ELEMS;
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
+  const int c0 = blockIdx.x * COLS, rp = blockIdx.y, b = blockIdx.z;   // rows 2rp, 2rp+1 of the p1 geometry
+
+  // wT[ci][(ah*3+aw)*32 + o] = w[o][ci][2-ah][2-aw]
+  for (int i = t; i < 16 * KP; i += 256) {
+    const int ci = i / KP, k = i % KP;
+    float v = 0.f;
+    if (k < 288) { const int tap = k >> 5, o = k & 31; v = w[(o * 16 + ci) * 9 + (8 - tap)]; }
+    w_s[i] = from_f32<T>(v);
+  }
+  stage_dc2<T, 4, WP, false>(dp2 + (int64_t)b * 32 * H2 * W2, code2 + (int64_t)b * 32 * H2 * W2, H2, W2, 2 * rp - 1,
+                             c0 - 1, dc_s, nullptr);
+  __syncthreads();
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[d][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int colb = 32 * wv + lr;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks) {           // one tap (32 channels) per k-step
+      const int ah = ks / 3, aw = ks % 3;
+      const bf16x8 a = *(const bf16x8*)&w_s[lr * KP + 32 * ks + 8 * lg];
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bf16x8 bb = *(const bf16x8*)&dc_s[((d + ah) * WP + colb + 16 * j + aw) * S32 + 8 * lg];
+          acc[d][j] = mfma16(a, bb, acc[d][j]);
+        }
+    }
+  } else {
+#pragma unroll 4
+    for (int ks = 0; ks < 72; ++ks) {
+      const int tap = ks >> 3, o = 4 * (ks & 7) + lg;
+      const int ah = tap / 3, aw = tap % 3;
+      const float a = w_s[lr * KP + 4 * ks + lg];
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float bb = dc_s[((d + ah) * WP + colb + 16 * j + aw) * S32 + o];
+          acc[d][j] = mfma16(a, bb, acc[d][j]);
+        }
+    }
+  }
+  // C layout: col (lr) = pixel, row (4*lg + r) = input channel -> 4 consecutive channels per lane, channels-last store
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ih = 2 * rp + d, iw = c0 + colb + 16 * j;
+      if (ih < H1 && iw < W1) {
+        T* dst = dp1 + (((int64_t)b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
+        if constexpr (sizeof(T) == 2) {
+          bf16x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[d][j][r];
+          *(bf16x4*)dst = v;
+        } else {
+          *(f32x4*)dst = acc[d][j];
+        }
+      }
+    }
+}
+
+// =====================================================================================================================
+// conv2 backward (weights): dW2[o][ci][kh][kw] = sum_{b,r,c} dc2[r][c][o] * p1[r-1+kh][c-1+kw][ci];  db2[o] = sum dc2
+// GEMM with M = 32 (o), N = 9 taps x 16 ci, K = pixels.  A workgroup walks units (image, row pair, column
+// super-tile); per unit it stages dc2 rows (2 x 128 x 32) and the p1 halo band (4 x 130 x 16) in LDS as
+// [pixel][channel] and each wave contracts its 32-column slice: bf16 reads both operands with the transposing
+// ds_read_b64_tr_b16 (the contraction index is the pixel, the LDS images are channel-contiguous).
+// Accumulators (2 x 9 tiles per wave) live in registers across all units, then waves are summed through LDS in fixed
+// order and the workgroup writes one slab; a second kernel sums the slabs in order (deterministic).
+// =====================================================================================================================
+template <typename T> struct W2c {
+  static constexpr int S16 = Px<T>::S16, S32 = Px<T>::S32;
+  static constexpr int DC_ELEMS = 2 * COLS * S32;
+  static constexpr int P_ELEMS = 4 * (COLS + 2) * S16;
+};
+
+__device__ __forceinline__ bf16x4 lds_tr16(const __bf16* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restrict__ dp2,
+                                                               const uint8_t* __restrict__ code2,
+                                                               const T* __restrict__ p1, int B, int H1, int W1,
+                                                               int H2, int W2, int n_ctiles, int n_units,
+                                                               float* __restrict__ slabs) {
+  constexpr int S16 = W2c<T>::S16, S32 = W2c<T>::S32, WP = COLS + 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  T* dc_s = (T*)dyn_smem;
+  T* p_s = dc_s + W2c<T>::DC_ELEMS;
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
+  f32x4 acc[2][9];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int n = 0; n < 9; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+  const int nrp = (H1 + 1) / 2;
+
+  for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
+    const int ct = u % n_ctiles, rp = (u / n_ctiles) % nrp, b = u / (n_ctiles * nrp);
+    const int c0 = ct * COLS;
+    __syncthreads();   // previous unit's readers are done
+    stage_dc2<T, 2, COLS, true>(dp2 + (int64_t)b * 32 * H2 * W2, code2 + (int64_t)b * 32 * H2 * W2, H2, W2, 2 * rp, c0,
+                                dc_s, bsum);
+    {
+      constexpr int PIECES = (sizeof(T) == 2) ? 2 : 4, EPP = 16 / PIECES;
+      const T* src = p1 + (int64_t)b * H1 * W1 * 16;
+      for (int i = t; i < 4 * WP * PIECES; i += 256) {
+        const int piece = i % PIECES, pix = i / PIECES;
+        const int cl = pix % WP, rl = pix / WP;
+        const int r = 2 * rp - 1 + rl, c = c0 - 1 + cl;
+        T* dst = p_s + (rl * WP + cl) * S16 + piece * EPP;
+        if (r >= 0 && r < H1 && c >= 0 && c < W1) {
+          const T* s = src + ((int64_t)r * W1 + c) * 16 + piece * EPP;
+          if constexpr (sizeof(T) == 2) *(bf16x8*)dst = *(const bf16x8*)s;
+          else { const f32x4 v = *(const f32x4*)s; dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPP; ++e) dst[e] = from_f32<T>(0.f);
+        }
+      }
+    }
+    __syncthreads();
+    // wave wv contracts conv cols [32wv, 32wv+32) of both rows
+    if constexpr (sizeof(T) == 2) {
+      const int q = lr >> 2, p = lr & 3;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const int cb = 32 * wv + 8 * lg;   // this lane group's 8 pixels: cols cb .. cb+7 of row d
+        bf16x8 a[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bf16x4 lo = lds_tr16(&dc_s[(d * COLS + cb + q) * S32 + 16 * i + 4 * p]);
+          const bf16x4 hi = lds_tr16(&dc_s[(d * COLS + cb + 4 + q) * S32 + 16 * i + 4 * p]);
+          a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int kh = tap / 3, kw = tap % 3;
+          const bf16x4 lo = lds_tr16(&p_s[((d + kh) * WP + cb + kw + q) * S16 + 4 * p]);
+          const bf16x4 hi = lds_tr16(&p_s[((d + kh) * WP + cb + kw + 4 + q) * S16 + 4 * p]);
+          const bf16x8 bb = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][tap] = mfma16(a[i], bb, acc[i][tap]);
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int d = 0; d < 2; ++d)
+#pragma unroll 2
+        for (int ks = 0; ks < 8; ++ks) {
+          const int cpix = 32 * wv + 4 * ks + lg;
+          float a[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[i] = dc_s[(d * COLS + cpix) * S32 + 16 * i + lr];
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;
+            const float bb = p_s[((d + kh) * WP + cpix + kw) * S16 + lr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][tap] = mfma16(a[i], bb, acc[i][tap]);
+          }
+        }
+    }
+  }
+  // ---- cross-wave reduction (fixed order) and slab write.  slab layout: [o 32][tap 9][ci 16] then 32 bias sums.
+  __syncthreads();
+  float* red = (float*)dyn_smem;   // 4 waves x 4608 floats = 73.7 KB (fits the dynamic allocation, see host)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 16 * i + 4 * lg + r;      // C row = M = o
+        red[wv * 4608 + (o * 9 + tap) * 16 + lr] = acc[i][tap][r];   // C col = N = ci
+      }
+  __syncthreads();
+  float* slab = slabs + (int64_t)blockIdx.x * (4608 + 32);
+  for (int i = t; i < 4608; i += 256) slab[i] = ((red[i] + red[4608 + i]) + red[2 * 4608 + i]) + red[3 * 4608 + i];
+  __syncthreads();
+  // bias sums: lane keeps channel group (t&3); reduce the 64 lanes-with-same-group x 8 channels through LDS
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[t * 8 + e] = bsum[e];
+  __syncthreads();
+  if (t < 32) {
+    const int og = t >> 3, e = t & 7;
+    float s = 0.f;
+    for (int k = 0; k < 64; ++k) s += red[(4 * k + og) * 8 + e];
+    slab[4608 + t] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void conv2_bwd_weight_final(const float* __restrict__ slabs, int nslabs,
+                                                              float* __restrict__ dw, float* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 4608 + 32) return;
+  float s = 0.f;
+  for (int k = 0; k < nslabs; ++k) s += slabs[(int64_t)k * (4608 + 32) + i];
+  if (i < 4608) {
+    const int ci = i & 15, tap = (i >> 4) % 9, o = i / 144;
+    dw[(o * 16 + ci) * 9 + tap] = s;
+  } else {
+    db[i - 4608] = s;
+  }
+}
+
+inline int conv1_slabs(int64_t total) {
+  int64_t b = (total + 256 * 8 - 1) / (256 * 8);
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+inline int conv2w_blocks(int n_units) { return n_units < 512 ? n_units : 512; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------- C ABI
+#define DISPATCH_T(dtype, CALL)                  \
+  if ((dtype) == GDM_BF16) { using T = __bf16; CALL; } else { using T = float; CALL; }
+
+extern "C" int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* bias, int B, int H, int W, void* p1,
+                                   uint64_t* code1, int dtype, void* stream) {
+  GDM_REQUIRE(x && w && bias && p1 && code1, "gdm_simnn_conv1_fwd: null pointer");
+  GDM_REQUIRE(B > 0 && H >= 1 && W >= 1 && gdm_dtype_ok(dtype), "gdm_simnn_conv1_fwd: bad arguments");
+  const int H1 = (H + 1) / 2, W1 = (W + 1) / 2;
+  const int64_t total = (int64_t)B * H1 * W1;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 65535 * 16) blocks = 65535 * 16;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                                       x, w, bias, B, H, W, H1, W1, (T*)p1, code1));
+  GDM_LAUNCH_OK("gdm_simnn_conv1_fwd");
+  return GDM_OK;
+}
+
+extern "C" size_t gdm_simnn_conv1_bwd_weight_workspace_bytes(int B, int H, int W) {
+  const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+  return (size_t)conv1_slabs(total) * 80 * sizeof(float);
+}
+
+extern "C" int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1, const float* x, int B, int H, int W,
+                                          float* dw, float* db, int dtype, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+  GDM_REQUIRE(dp1 && code1 && x && dw && db, "gdm_simnn_conv1_bwd_weight: null pointer");
+  GDM_REQUIRE(B > 0 && H >= 1 && W >= 1 && gdm_dtype_ok(dtype), "gdm_simnn_conv1_bwd_weight: bad arguments");
+  if (!workspace || workspace_bytes < gdm_simnn_conv1_bwd_weight_workspace_bytes(B, H, W)) {
+    gdm_set_error("gdm_simnn_conv1_bwd_weight: workspace too small");
+    return GDM_EWORKSPACE;
+  }
+  const int H1 = (H + 1) / 2, W1 = (W + 1) / 2;
+  const int nslabs = conv1_slabs((int64_t)B * H1 * W1);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_bwd_weight_kernel<T>, dim3(nslabs), dim3(256), 0, s, (const T*)dp1, code1,
+                                       x, B, H, W, H1, W1, (float*)workspace));
+  hipLaunchKernelGGL(conv1_bwd_weight_final, dim3(1), dim3(128), 0, s, (const float*)workspace, nslabs, dw, db);
+  GDM_LAUNCH_OK("gdm_simnn_conv1_bwd_weight");
+  return GDM_OK;
+}
+
+extern "C" int gdm_simnn_conv2_fwd(const void* p1, const float* w, const float* bias, int B, int H1, int W1, void* p2,
+                                   uint8_t* code2, int dtype, void* stream) {
+  GDM_REQUIRE(p1 && w && bias && p2 && code2, "gdm_simnn_conv2_fwd: null pointer");
+  GDM_REQUIRE(B > 0 && B <= 65535 && H1 >= 2 && W1 >= 2 && gdm_dtype_ok(dtype), "gdm_simnn_conv2_fwd: bad arguments");
+  const int H2 = H1 / 2, W2 = W1 / 2;
+  GDM_REQUIRE(H2 <= 65535, "gdm_simnn_conv2_fwd: H too large");
+  dim3 grid((2 * W2 + COLS - 1) / COLS, H2, B);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(conv2_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)p1, w,
+                                       bias, H1, W1, H2, W2, (T*)p2, code2));
+  GDM_LAUNCH_OK("gdm_simnn_conv2_fwd");
+  return GDM_OK;
+}
+
+extern "C" int gdm_simnn_conv2_bwd_data(const void* dp2, const uint8_t* code2, const float* w, int B, int H1, int W1,
+                                        void* dp1, int dtype, void* stream) {
+  GDM_REQUIRE(dp2 && code2 && w && dp1, "gdm_simnn_conv2_bwd_data: null pointer");
+  GDM_REQUIRE(B > 0 && B <= 65535 && H1 >= 2 && W1 >= 2 && gdm_dtype_ok(dtype),
+              "gdm_simnn_conv2_bwd_data: bad arguments");
+  const int H2 = H1 / 2, W2 = W1 / 2;
+  dim3 grid((W1 + COLS - 1) / COLS, (H1 + 1) / 2, B);
+  GDM_REQUIRE(grid.y <= 65535, "gdm_simnn_conv2_bwd_data: H too large");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == GDM_BF16) {
+    const size_t sm = (size_t)(D2<__bf16>::DC_ELEMS + D2<__bf16>::W_ELEMS) * 2;
+    hipLaunchKernelGGL(conv2_bwd_data_kernel<__bf16>, grid, dim3(256), sm, s, (const __bf16*)dp2, code2, w, H1, W1, H2,
+                       W2, (__bf16*)dp1);
+  } else {
+    const size_t sm = (size_t)(D2<float>::DC_ELEMS + D2<float>::W_ELEMS) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv2_bwd_data_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sm);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(conv2_bwd_data_kernel<float>, grid, dim3(256), sm, s, (const float*)dp2, code2, w, H1, W1, H2,
+                       W2, (float*)dp1);
+  }
+  GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_data");
+  return GDM_OK;
+}
+
+extern "C" size_t gdm_simnn_conv2_bwd_weight_workspace_bytes(int B, int H1, int W1) {
+  const int n_units = B * ((H1 + 1) / 2) * ((W1 + COLS - 1) / COLS);
+  return (size_t)conv2w_blocks(n_units) * (4608 + 32) * sizeof(float);
+}
+
+extern "C" int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2, const void* p1, int B, int H1, int W1,
+                                          float* dw, float* db, int dtype, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+  GDM_REQUIRE(dp2 && code2 && p1 && dw && db, "gdm_simnn_conv2_bwd_weight: null pointer");
+  GDM_REQUIRE(B > 0 && H1 >= 2 && W1 >= 2 && gdm_dtype_ok(dtype), "gdm_simnn_conv2_bwd_weight: bad arguments");
+  if (!workspace || workspace_bytes < gdm_simnn_conv2_bwd_weight_workspace_bytes(B, H1, W1)) {
+    gdm_set_error("gdm_simnn_conv2_bwd_weight: workspace too small");
+    return GDM_EWORKSPACE;
+  }
+  const int H2 = H1 / 2, W2 = W1 / 2;
+  const int n_ctiles = (W1 + COLS - 1) / COLS;
+  const int n_units = B * ((H1 + 1) / 2) * n_ctiles;
+  const int nblocks = conv2w_blocks(n_units);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t red_bytes = (size_t)4 * 4608 * sizeof(float);
+  if (dtype == GDM_BF16) {
+    size_t sm = (size_t)(W2c<__bf16>::DC_ELEMS + W2c<__bf16>::P_ELEMS) * 2;
+    if (sm < red_bytes) sm = red_bytes;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv2_bwd_weight_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sm);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(conv2_bwd_weight_kernel<__bf16>, dim3(nblocks), dim3(256), sm, s, (const __bf16*)dp2, code2,
+                       (const __bf16*)p1, B, H1, W1, H2, W2, n_ctiles, n_units, (float*)workspace);
+  } else {
+    size_t sm = (size_t)(W2c<float>::DC_ELEMS + W2c<float>::P_ELEMS) * 4;
+    if (sm < red_bytes) sm = red_bytes;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv2_bwd_weight_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)sm);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(conv2_bwd_weight_kernel<float>, dim3(nblocks), dim3(256), sm, s, (const float*)dp2, code2,
+                       (const float*)p1, B, H1, W1, H2, W2, n_ctiles, n_units, (float*)workspace);
+  }
+  hipLaunchKernelGGL(conv2_bwd_weight_final, dim3((4608 + 32 + 255) / 256), dim3(256), 0, s, (const float*)workspace,
+                     nblocks, dw, db);
+  GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_weight");
+  return GDM_OK;
+}

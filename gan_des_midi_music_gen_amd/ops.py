@@ -1,0 +1,269 @@
+"""Tensor-level wrappers over the C ABI (include/gdm.h).
+
+PyTorch is used here only for device memory (caching allocator) and the current HIP stream; every wrapper checks
+that its tensors live on a HIP device and raises otherwise -- there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F32, GdmError, check  # noqa: F401
+
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def torch_dtype(dt):
+    return _TORCH_DT[dt]
+
+
+def gdm_dtype(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise GdmError(f"unsupported tensor dtype {t.dtype} (fp32 or bf16 only)")
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise GdmError("gan_des_midi_music_gen_amd ops run on a HIP device only (tensor is on "
+                           f"{t.device}); there is no CPU fallback")
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only per-device scratch buffer; safe because every consumer is ordered on the same stream."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def default_split_k(m, n, k, compute):
+    kt = 64 if compute == BF16 else 32
+    tiles = ((m + 63) // 64) * ((n + 63) // 64)
+    ktiles = (k + kt - 1) // kt
+    if tiles >= 256 or ktiles < 16:
+        return 1
+    return max(1, min(ktiles // 8, (1024 + tiles - 1) // tiles))
+
+
+def gemm(a, b, *, bias_n=None, bias_m=None, act=ACT_NONE, slope=0.0, out_dtype=None, compute=F32, split_k=None,
+         out=None):
+    """act(a @ b + bias): a (M,K), b (K,N) are arbitrary strided 2-D views (``.t()`` is free)."""
+    _need_gpu(a, b, bias_n, bias_m, out)
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[0], (a.shape, b.shape)
+    m, k = a.shape
+    n = b.shape[1]
+    if out is None:
+        out = torch.empty((m, n), dtype=_TORCH_DT[F32 if out_dtype is None else out_dtype], device=a.device)
+    assert out.shape == (m, n)
+    if split_k is None:
+        split_k = default_split_k(m, n, k, compute)
+    ws, ws_bytes = None, 0
+    if split_k > 1:
+        ws_bytes = split_k * m * n * 4
+        ws = workspace(ws_bytes, a.device)
+    lib = _lib.load()
+    check(lib.gdm_gemm(_p(a), gdm_dtype(a), a.stride(0), a.stride(1), _p(b), gdm_dtype(b), b.stride(0), b.stride(1),
+                       _p(out), gdm_dtype(out), out.stride(0), out.stride(1), m, n, k, _p(bias_n), _p(bias_m), act,
+                       float(slope), compute, split_k, _p(ws), ws_bytes, _stream()), "gdm_gemm")
+    return out
+
+
+def bce_with_logits(x, target, *, grad_scale=1.0, want_grad=True, fuse_sigmoid_backward=False, loss_out=None):
+    """Returns (loss (1,) fp32 tensor, dx or None).  x: (n,) fp32 contiguous."""
+    _need_gpu(x)
+    x = x.reshape(-1)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x) if want_grad else None
+    check(_lib.load().gdm_bce_with_logits(_p(x), float(target), x.numel(), float(grad_scale), _p(loss), _p(dx),
+                                           1 if fuse_sigmoid_backward else 0, _stream()), "gdm_bce_with_logits")
+    return loss, dx
+
+
+def adam_step(p, g, m, v, step, lr, beta1, beta2, eps):
+    _need_gpu(p, g, m, v)
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
+    check(_lib.load().gdm_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), int(step), float(lr), float(beta1),
+                                    float(beta2), float(eps), _stream()), "gdm_adam_step")
+
+
+def bn_act_fwd(y, gamma, beta, running_mean, running_var, nbt, *, act, out_dtype=F32, training=True, momentum=0.1,
+               eps=1e-5):
+    """y (rows, C) fp32 -> (out, save_mean, save_invstd)."""
+    _need_gpu(y, gamma, beta, running_mean, running_var, nbt)
+    assert y.dim() == 2 and y.dtype == torch.float32 and y.is_contiguous()
+    rows, c = y.shape
+    out = torch.empty((rows, c), dtype=_TORCH_DT[out_dtype], device=y.device)
+    mean = torch.empty(c, dtype=torch.float32, device=y.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=y.device)
+    lib = _lib.load()
+    nb = lib.gdm_bn_workspace_bytes(rows, c)
+    ws = workspace(nb, y.device)
+    check(lib.gdm_bn_act_fwd(_p(y), rows, c, _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(nbt),
+                             float(momentum), float(eps), act, _p(out), out_dtype, _p(mean), _p(invstd),
+                             1 if training else 0, _p(ws), nb, _stream()), "gdm_bn_act_fwd")
+    return out, mean, invstd
+
+
+def bn_act_bwd(dout, out, y, gamma, mean, invstd, *, act):
+    _need_gpu(dout, out, y, gamma, mean, invstd)
+    rows, c = y.shape
+    assert dout.dtype == out.dtype and dout.is_contiguous() and out.is_contiguous() and y.is_contiguous()
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
+    lib = _lib.load()
+    nb = lib.gdm_bn_workspace_bytes(rows, c)
+    ws = workspace(nb, y.device)
+    check(lib.gdm_bn_act_bwd(_p(dout), _p(out), gdm_dtype(out), _p(y), rows, c, _p(gamma), _p(mean), _p(invstd), act,
+                             _p(dy), _p(dgamma), _p(dbeta), _p(ws), nb, _stream()), "gdm_bn_act_bwd")
+    return dy, dgamma, dbeta
+
+
+def bias_act_fwd(x, bias, *, act, slope=0.0, out_dtype=F32):
+    _need_gpu(x, bias)
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty(x.shape, dtype=_TORCH_DT[out_dtype], device=x.device)
+    check(_lib.load().gdm_bias_act_fwd(_p(x), _p(bias), x.shape[0], x.shape[1], act, float(slope), _p(out), out_dtype,
+                                       _stream()), "gdm_bias_act_fwd")
+    return out
+
+
+def act_bwd(dout, out, *, act, slope=0.0):
+    _need_gpu(dout, out)
+    assert dout.dtype == out.dtype and dout.is_contiguous() and out.is_contiguous() and dout.numel() == out.numel()
+    dx = torch.empty_like(dout)
+    check(_lib.load().gdm_act_bwd(_p(dout), _p(out), gdm_dtype(out), out.numel(), act, float(slope), _p(dx),
+                                  _stream()), "gdm_act_bwd")
+    return dx
+
+
+def colsum(x):
+    _need_gpu(x)
+    assert x.dim() == 2 and x.is_contiguous()
+    rows, c = x.shape
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    nb = ((rows + 63) // 64 + 1) * c * 4
+    ws = workspace(nb, x.device)
+    check(_lib.load().gdm_colsum(_p(x), gdm_dtype(x), rows, c, _p(out), _p(ws), nb, _stream()), "gdm_colsum")
+    return out
+
+
+def cast(x, dt):
+    _need_gpu(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=_TORCH_DT[dt], device=x.device)
+    check(_lib.load().gdm_cast(_p(x), gdm_dtype(x), _p(out), dt, x.numel(), _stream()), "gdm_cast")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ model 1 conv trunk
+def simnn_conv1_fwd(x, w, bias, dt):
+    _need_gpu(x, w, bias)
+    assert x.dim() == 3 and x.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()
+    b, h, wd = x.shape
+    h1, w1 = (h + 1) // 2, (wd + 1) // 2
+    p1 = torch.empty((b, h1, w1, 16), dtype=_TORCH_DT[dt], device=x.device)
+    code1 = torch.empty((b, h1, w1), dtype=torch.int64, device=x.device)
+    check(_lib.load().gdm_simnn_conv1_fwd(_p(x), _p(w), _p(bias), b, h, wd, _p(p1), _p(code1), dt, _stream()),
+          "gdm_simnn_conv1_fwd")
+    return p1, code1
+
+
+def simnn_conv2_fwd(p1, w, bias):
+    _need_gpu(p1, w, bias)
+    assert p1.dim() == 4 and p1.shape[3] == 16 and p1.is_contiguous() and w.is_contiguous()
+    b, h1, w1, _ = p1.shape
+    h2, w2 = h1 // 2, w1 // 2
+    p2 = torch.empty((b, 32, h2, w2), dtype=p1.dtype, device=p1.device)
+    code2 = torch.empty((b, 32, h2, w2), dtype=torch.uint8, device=p1.device)
+    check(_lib.load().gdm_simnn_conv2_fwd(_p(p1), _p(w), _p(bias), b, h1, w1, _p(p2), _p(code2), gdm_dtype(p1),
+                                          _stream()), "gdm_simnn_conv2_fwd")
+    return p2, code2
+
+
+def simnn_conv2_bwd_data(dp2, code2, w, h1, w1):
+    _need_gpu(dp2, code2, w)
+    assert dp2.is_contiguous() and code2.is_contiguous() and w.is_contiguous()
+    b = dp2.shape[0]
+    dp1 = torch.empty((b, h1, w1, 16), dtype=dp2.dtype, device=dp2.device)
+    check(_lib.load().gdm_simnn_conv2_bwd_data(_p(dp2), _p(code2), _p(w), b, h1, w1, _p(dp1), gdm_dtype(dp2),
+                                               _stream()), "gdm_simnn_conv2_bwd_data")
+    return dp1
+
+
+def simnn_conv2_bwd_weight(dp2, code2, p1):
+    _need_gpu(dp2, code2, p1)
+    assert dp2.is_contiguous() and code2.is_contiguous() and p1.is_contiguous() and dp2.dtype == p1.dtype
+    b, h1, w1, _ = p1.shape
+    dw = torch.empty((32, 16, 3, 3), dtype=torch.float32, device=p1.device)
+    db = torch.empty(32, dtype=torch.float32, device=p1.device)
+    lib = _lib.load()
+    nb = lib.gdm_simnn_conv2_bwd_weight_workspace_bytes(b, h1, w1)
+    ws = workspace(nb, p1.device)
+    check(lib.gdm_simnn_conv2_bwd_weight(_p(dp2), _p(code2), _p(p1), b, h1, w1, _p(dw), _p(db), gdm_dtype(p1), _p(ws),
+                                         nb, _stream()), "gdm_simnn_conv2_bwd_weight")
+    return dw, db
+
+
+def simnn_conv1_bwd_weight(dp1, code1, x):
+    _need_gpu(dp1, code1, x)
+    assert dp1.is_contiguous() and code1.is_contiguous() and x.is_contiguous()
+    b, h, wd = x.shape
+    dw = torch.empty((16, 1, 2, 2), dtype=torch.float32, device=x.device)
+    db = torch.empty(16, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nb = lib.gdm_simnn_conv1_bwd_weight_workspace_bytes(b, h, wd)
+    ws = workspace(nb, x.device)
+    check(lib.gdm_simnn_conv1_bwd_weight(_p(dp1), _p(code1), _p(x), b, h, wd, _p(dw), _p(db), gdm_dtype(dp1), _p(ws),
+                                         nb, _stream()), "gdm_simnn_conv1_bwd_weight")
+    return dw, db
+
+
+# ------------------------------------------------------------------------------------------ patch lowering
+def im2col(src, *, planar, b, h, w, c, kh, kw, stride, pad, out_dtype):
+    _need_gpu(src)
+    assert src.is_contiguous()
+    oh = (h + 2 * pad - kh) // stride + 1
+    ow = (w + 2 * pad - kw) // stride + 1
+    cols = torch.empty((b * oh * ow, c * kh * kw), dtype=_TORCH_DT[out_dtype], device=src.device)
+    check(_lib.load().gdm_im2col(_p(src), gdm_dtype(src), 1 if planar else 0, b, h, w, c, kh, kw, stride, pad, oh, ow,
+                                 _p(cols), out_dtype, _stream()), "gdm_im2col")
+    return cols, oh, ow
+
+
+def col2im(cols, *, b, h, w, c, kh, kw, stride, pad, oh, ow, out_dtype, planar=False):
+    _need_gpu(cols)
+    assert cols.is_contiguous() and cols.shape == (b * oh * ow, c * kh * kw)
+    shape = (b, c, h, w) if planar else (b, h, w, c)
+    dst = torch.empty(shape, dtype=_TORCH_DT[out_dtype], device=cols.device)
+    check(_lib.load().gdm_col2im(_p(cols), gdm_dtype(cols), b, h, w, c, kh, kw, stride, pad, oh, ow, _p(dst),
+                                 out_dtype, 1 if planar else 0, _stream()), "gdm_col2im")
+    return dst
+
+
+def permute_pc(src, b, p, c):
+    """(B, P, C) -> (B, C, P), same dtype (channels-last <-> channel-major)."""
+    _need_gpu(src)
+    assert src.is_contiguous() and src.numel() == b * p * c
+    dst = torch.empty((b, c, p), dtype=src.dtype, device=src.device)
+    check(_lib.load().gdm_permute_pc(_p(src), gdm_dtype(src), b, p, c, _p(dst), _stream()), "gdm_permute_pc")
+    return dst

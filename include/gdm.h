@@ -1,0 +1,133 @@
+/*
+ * gdm.h -- C ABI of libgdm_hip.so: the MI355X (gfx950) kernels under the GAN training hot path of
+ * marja-w/gan-des-midi-music-gen (GAN_DES/SIMNN.py, MMGAN_MIDI_DES/network_tests.py).
+ *
+ * The reference has no native/FFI boundary of its own: everything below its Python classes is
+ * PyTorch/ATen.  Each entry point here therefore names the ATen dispatch (and the reference call site) it replaces.
+ *
+ * Contract (all entry points):
+ *   - plain C: device pointers + sizes, no torch types; `stream` is a hipStream_t passed as void*.
+ *   - caller owns all memory; nothing is allocated, freed or synchronised here; work is only enqueued on `stream`.
+ *   - returns 0 on success, a negative GDM_E* code otherwise; gdm_last_error() gives the thread-local message.
+ *   - re-entrant across host threads (autograd runs backward on its own thread); no global mutable state.
+ *   - `dtype` arguments: GDM_F32 (exact-fp32 mode, v_mfma_f32_16x16x4_f32) or GDM_BF16 (bf16 storage/MFMA operands,
+ *     v_mfma_f32_16x16x32_bf16, fp32 accumulation).  Parameters, gradients of parameters, optimizer state, batch-norm
+ *     statistics and losses are always fp32.
+ */
+#ifndef GDM_H
+#define GDM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { GDM_F32 = 0, GDM_BF16 = 1 };
+enum { GDM_ACT_NONE = 0, GDM_ACT_RELU = 1, GDM_ACT_LEAKY = 2, GDM_ACT_SIGMOID = 3 };
+enum { GDM_OK = 0, GDM_EINVAL = -1, GDM_ELAUNCH = -2, GDM_EWORKSPACE = -3 };
+
+/* ---- probes -------------------------------------------------------------------------------------------------- */
+const char* gdm_last_error(void);
+int gdm_version(void);          /* 1000*major + minor */
+const char* gdm_arch(void);     /* "gfx950" */
+
+/* ---- dense layers (aten::addmm / aten::mm: nn.Linear fwd, dX, dW; ConvTranspose2d as GEMM) ---------------------
+ * C[m,n] = act( sum_k A[m,k]*B[k,n] + bias_n[n] + bias_m[m] ), arbitrary element strides (transposes are free).
+ * Replaces F.linear at SIMNN.py:140-141, network_tests.py:77,112,139,160 and their autograd mm's.
+ * compute_dtype selects the MFMA; operands of the other type are converted while staged into LDS.
+ * split_k > 1 partitions K over blockIdx.z into fp32 slabs in `workspace` (>= split_k*M*N*4 bytes) that a second
+ * kernel sums in fixed order (deterministic) before bias/activation.                                              */
+int gdm_gemm(const void* A, int a_dtype, int64_t sam, int64_t sak,
+             const void* B, int b_dtype, int64_t sbk, int64_t sbn,
+             void* C, int c_dtype, int64_t scm, int64_t scn,
+             int M, int N, int K,
+             const float* bias_n, const float* bias_m, int act, float slope,
+             int compute_dtype, int split_k, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- loss (aten::binary_cross_entropy_with_logits, mean) --------------------------------------------------------
+ * x: n fp32 values fed to BCEWithLogitsLoss (for model 1 these are already sigmoid outputs: SIMNN.py:141 + 289),
+ * target: one label value for the whole batch (0.9/0.1/1.0 at SIMNN.py:284,308,326; 1/0 at network_tests.py:286-287).
+ * Writes loss[0] (mean) and, if dx != NULL, dx[i] = grad_scale * (sigmoid(x[i]) - target) / n.
+ * If pre_sigmoid_z != NULL the chain through model 1's final sigmoid is fused: x[i] must equal sigmoid(z[i]) and
+ * dx[i] is d loss / d z[i].  n <= 65536 (one workgroup, fixed-order reduction => deterministic).                   */
+int gdm_bce_with_logits(const float* x, float target, int n, float grad_scale, float* loss, float* dx,
+                        int fuse_sigmoid_backward, void* stream);
+
+/* ---- optimizer (torch.optim.Adam single-tensor step, SIMNN.py:258-259,316; network_tests.py:253-254,308) -------
+ * One flat fp32 range: p, g, m (exp_avg), v (exp_avg_sq) of n elements; `step` is the 1-based step count.
+ * bias corrections are computed on the host in double like torch does.                                            */
+int gdm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
+                  float beta2, float eps, void* stream);
+
+/* ---- batch norm, training mode, rows x channels matrices (aten::native_batch_norm + activation) ----------------
+ * y: (rows, channels) fp32 pre-norm values (row-major).  Computes per-channel batch mean / biased variance with a
+ * fixed-order Welford merge, updates running_mean/var (momentum, unbiased var) and num_batches_tracked, and writes
+ * out = act(gamma*(y-mean)*invstd + beta) in `out_dtype`.  save_mean/save_invstd (channels) are kept for backward.
+ * Covers BatchNorm1d+Sigmoid (network_tests.py:78-79,113-114; rows=B) and BatchNorm2d+ReLU on channels-last
+ * activations (SIMNN.py:105-108; rows=B*H*W).  workspace >= gdm_bn_workspace_bytes(rows, channels).
+ * training=0 normalises with the running statistics instead and leaves them untouched.                            */
+size_t gdm_bn_workspace_bytes(int rows, int channels);
+int gdm_bn_act_fwd(const float* y, int rows, int channels, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                   int act, void* out, int out_dtype, float* save_mean, float* save_invstd, int training,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* dout: gradient w.r.t. `out` (out_dtype); out: the forward's output (used for act'); y: the pre-norm input.
+ * Writes dy (rows,channels) fp32 and dgamma/dbeta (channels).                                                     */
+int gdm_bn_act_bwd(const void* dout, const void* out, int out_dtype, const float* y, int rows, int channels,
+                   const float* gamma, const float* save_mean, const float* save_invstd, int act, float* dy,
+                   float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- elementwise helpers ---------------------------------------------------------------------------------------*/
+/* out = act(x + bias[col]) and its backward dx = dout * act'(out); (rows, cols) row-major. */
+int gdm_bias_act_fwd(const float* x, const float* bias, int rows, int cols, int act, float slope, void* out,
+                     int out_dtype, void* stream);
+int gdm_act_bwd(const void* dout, const void* out, int dtype, int64_t n, int act, float slope, void* dx, void* stream);
+/* column sums of a (rows, cols) matrix: out[c] = sum_r x[r,c] (bias gradients). deterministic two-stage. */
+int gdm_colsum(const void* x, int dtype, int rows, int cols, float* out, void* workspace, size_t workspace_bytes,
+               void* stream);
+int gdm_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+
+/* ---- model 1 discriminator, convolution trunk (SIMNN.py:123-125,136-139) ---------------------------------------
+ * conv1: Conv2d(1,16,k2,s1,p1)+ReLU+MaxPool2 fused (aten::convolution/relu/max_pool2d_with_indices):
+ *   x (B,H,W) fp32 -> p1 (B,H1,W1,16) channels-last `dtype`, code1 (B,H1,W1) uint64: bits [2c+1:2c] = argmax
+ *   position (dy*2+dx, first maximum in scan order) of channel c, bit 32+c = channel c passes gradient
+ *   (pooled value > 0); H1=(H+1)/2, W1=(W+1)/2.
+ * conv2: Conv2d(16,32,k3,s1,p1)+ReLU+MaxPool2 fused, implicit GEMM on MFMA:
+ *   p1 -> p2 (B,32,H2,W2) channel-major (the reference's flatten order, so fc1 is a plain GEMM), code2 (B,32,H2,W2)
+ *   uint8 (0..3 = argmax position in scan order, 4 = ReLU-dead), H2=H1/2, W2=W1/2.                                */
+int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* bias, int B, int H, int W, void* p1,
+                        uint64_t* code1, int dtype, void* stream);
+int gdm_simnn_conv2_fwd(const void* p1, const float* w, const float* bias, int B, int H1, int W1, void* p2,
+                        uint8_t* code2, int dtype, void* stream);
+/* backward of the conv2 block w.r.t. its input: dp2 (B,32,H2,W2) + code2 -> dp1 (B,H1,W1,16).  conv1's ReLU/pool
+ * routing is not applied here; gdm_simnn_conv1_bwd_weight applies it through code1. */
+int gdm_simnn_conv2_bwd_data(const void* dp2, const uint8_t* code2, const float* w, int B, int H1, int W1, void* dp1,
+                             int dtype, void* stream);
+/* dW2 (32,16,3,3), db2 (32): deterministic slab reduction; workspace >= gdm_simnn_conv2_bwd_weight_workspace_bytes */
+size_t gdm_simnn_conv2_bwd_weight_workspace_bytes(int B, int H1, int W1);
+int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2, const void* p1, int B, int H1, int W1,
+                               float* dw, float* db, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* dW1 (16,1,2,2), db1 (16) from dp1 routed through code1 (pool argmax + ReLU mask) and the input x. */
+size_t gdm_simnn_conv1_bwd_weight_workspace_bytes(int B, int H, int W);
+int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1, const float* x, int B, int H, int W,
+                               float* dw, float* db, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- generic convolution lowering helpers (model 2 discriminator, model 1 generator) ----------------------------
+ * im2col for Conv2d fwd / dW and col2im (gather form, deterministic) for Conv2d dX and ConvTranspose2d fwd.
+ * Activations are channels-last (B,H,W,C) unless `src_planar` (NCHW fp32 input planes, e.g. the piano-roll).
+ * cols: (B*OH*OW, C*KH*KW) row-major with k = (c*KH + kh)*KW + kw -- torch's weight order, so Conv2d weights
+ * (Cout, Cin*KH*KW) and ConvTranspose2d weights (Cin, Cout*KH*KW) are GEMM operands in place.                       */
+int gdm_im2col(const void* src, int src_dtype, int src_planar, int B, int H, int W, int C, int KH, int KW,
+               int stride, int pad, int OH, int OW, void* cols, int cols_dtype, void* stream);
+/* dst[b,h,w,c] = sum over (oh,ow,kh,kw) with oh*stride-pad+kh==h, ow*stride-pad+kw==w of cols[(b,oh,ow),(c,kh,kw)] */
+int gdm_col2im(const void* cols, int cols_dtype, int B, int H, int W, int C, int KH, int KW, int stride, int pad,
+               int OH, int OW, void* dst, int dst_dtype, int dst_planar, void* stream);
+
+/* dst (B,C,P) = src (B,P,C) transposed per batch element (channels-last <-> channel-major flatten order). */
+int gdm_permute_pc(const void* src, int dtype, int B, int P, int C, void* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDM_H */
