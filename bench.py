@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Benchmark of the GAN training hot path on MI355X: training samples/s for one full G+D iteration.
+
+    python bench.py --gpus N --steps K --warmup W [--workload simnn|mmgan] [--batch B] [--dtype bf16|fp32]
+                    [--mode faithful|elided] [--no-cpu-baseline]
+
+Default workload = BASELINE.json configs[1]: model 1 (GAN_DES/SIMNN.py) G+D iteration, 128x256 synthetic spectrogram
+windows, batch 256 per GPU, bf16 MFMA, reference-faithful iteration (1 G forward, 3 D forwards, 2 D backwards, Adam).
+N > 1: one process per GPU (torchrun env), per-GPU batch fixed (weak scaling), one RCCL all-reduce of the flat
+discriminator-gradient bucket per iteration.  Rank 0 prints ONE JSON line.
+
+Timing: W warm-up iterations, then exactly K iterations between barrier + device-synchronize brackets, wall clock,
+MAX over ranks.  Inputs are resident in HBM before the timed region.  A second, instrumented pass of K iterations
+brackets every launch of the dominant kernel with HIP events (on the launch stream) for the `roofline` object; the
+CPU oracle (oracle/, this repo's restatement of the reference loop) is timed on the host cores for `cpu_baseline`
+(rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32 (spec; 155 measured)
+
+# dominant kernel per workload/dtype and its ALGORITHMIC bytes / flops per sample (derivation in DESIGN.md section 5)
+def dominant_kernel(workload, dtype, hw, t):
+    if workload == "simnn":
+        h1, w1 = (hw[0] + 1) // 2, (hw[1] + 1) // 2
+        h2, w2 = h1 // 2, w1 // 2
+        esz = 2 if dtype == "bf16" else 4
+        # conv2 forward: read p1 (H1*W1*16), write p2 (32*H2*W2), activations only
+        return {"name": "gdm_simnn_conv2_fwd", "bytes_per_sample": (h1 * w1 * 16 + 32 * h2 * w2) * esz,
+                "flops_per_sample": 2.0 * h1 * w1 * 32 * 144}
+    esz = 2 if dtype == "bf16" else 4
+    oh2, ow2 = 128 // 4, t // 4
+    # model 2: the conv2 GEMM of DiscriminatorCNN (im2col rows x 256 -> 32 channels)
+    return {"name": "gdm_gemm", "bytes_per_sample": (oh2 * ow2 * 256 + oh2 * ow2 * 32) * esz,
+            "flops_per_sample": 2.0 * oh2 * ow2 * 256 * 32}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="simnn", choices=["simnn", "mmgan"])
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default="faithful", choices=["faithful", "elided"])
+    ap.add_argument("--width", type=int, default=256, help="spectrogram window width (simnn)")
+    ap.add_argument("--seq", type=int, default=50, help="piano-roll length T (mmgan)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def setup_dist(n):
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if n > 1 or world > 1:
+        if world != n:
+            raise SystemExit(f"--gpus {n} needs torchrun with {n} ranks (WORLD_SIZE={world})")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        return dist.get_rank(), world, local
+    torch.cuda.set_device(0)
+    return 0, 1, 0
+
+
+def build_simnn(args, rank, dev):
+    from gan_des_midi_music_gen_amd import SIMNN, synthetic
+    from gan_des_midi_music_gen_amd.train import SimnnTrainer
+    hw = (128, args.width)
+    torch.manual_seed(0)   # identical replicas on every rank
+    gen = SIMNN.Generator().apply(SIMNN.weights_init).to(dev)
+    disc = SIMNN.Discriminator(input_hw=hw).apply(SIMNN.weights_init).to(dev)
+    tr = SimnnTrainer(gen, disc, compute_dtype=args.dtype, elide_dead_backward=(args.mode == "elided"))
+    real, fake, noise = synthetic.simnn_inputs(args.batch, hw, seed=1234 + rank, device=dev)
+
+    def step():
+        return tr.step(real, noise, fake)
+    return tr, step
+
+
+def build_mmgan(args, rank, dev):
+    from gan_des_midi_music_gen_amd import network_tests as NT, synthetic
+    from gan_des_midi_music_gen_amd.train import MmganTrainer
+    torch.manual_seed(0)
+    mm = NT.MultiModalGAN(z_dim=50, adj_size=(64, 64), roll_size=(2, 128, args.seq), input_dim=50, output_dim=20,
+                          instrument=0, start=100, end=100 + args.seq, device=dev)
+    mm.train()
+    tr = MmganTrainer(mm, compute_dtype=args.dtype, elide_dead_backward=(args.mode == "elided"))
+    d = synthetic.mmgan_inputs(args.batch, args.seq, seed=1234 + rank, device=dev)
+
+    def step():
+        return tr.step(d["piano_roll"], d["durations"], d["beats"], d["noise1"], d["noise2"], d["fake_a"],
+                       d["fake_b"], g1_in_a=d["g1_in_a"], g1_in_b=d["g1_in_b"])
+    return tr, step
+
+
+def cpu_baseline(args):
+    """Oracle (CPU restatement of the reference loop) on the host cores; bounded sample, same geometry/mode."""
+    from oracle import simnn as osn, mmgan as om, steps as ost
+    from gan_des_midi_music_gen_amd import synthetic
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    elide = args.mode == "elided"
+    if args.workload == "simnn":
+        b, hw = 32, (128, args.width)
+        torch.manual_seed(0)
+        gen = osn.Generator().apply(osn.weights_init)
+        disc = osn.Discriminator(input_hw=hw).apply(osn.weights_init)
+        g_opt = ost.Adam(gen.parameters(), lr=0.00002, betas=(0.5, 0.999))
+        d_opt = ost.Adam(disc.parameters(), lr=0.00002, betas=(0.5, 0.999))
+        real, fake, noise = synthetic.simnn_inputs(b, hw, seed=1234)
+        fn = lambda: ost.simnn_iteration(gen, disc, g_opt, d_opt, real, noise, fake, elide)  # noqa: E731
+        sample = f"oracle.simnn_iteration, batch {b}, 128x{args.width}, fp32, {args.mode}"
+    else:
+        b = 256
+        torch.manual_seed(0)
+        mm = om.MultiModalGAN(z_dim=50, adj_size=(64, 64), roll_size=(2, 128, args.seq), input_dim=50, output_dim=20)
+        g_opt = ost.Adam(list(mm.generator1.parameters()) + list(mm.generator2.parameters()), lr=0.01)
+        d_opt = ost.Adam(mm.discriminator.parameters(), lr=0.01)
+        d = synthetic.mmgan_inputs(b, args.seq, seed=1234)
+        fn = lambda: ost.mmgan_iteration(mm, g_opt, d_opt, d["piano_roll"], d["durations"], d["beats"],  # noqa: E731
+                                         d["noise1"], d["noise2"], d["g1_in_a"], d["g1_in_b"], d["fake_a"],
+                                         d["fake_b"], 1, elide)
+        sample = f"oracle.mmgan_iteration, batch {b}, T={args.seq}, fp32, {args.mode}"
+    fn()
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        fn()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 12.0 or n >= 200:
+            break
+    return {"value": round(b * n / el, 2), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{sample}; {n} iterations in {el:.1f} s"}
+
+
+def main():
+    args = parse()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    rank, world, local = setup_dist(args.gpus)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    from gan_des_midi_music_gen_amd import ops
+
+    tr, step = (build_simnn if args.workload == "simnn" else build_mmgan)(args, rank, dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d_loss, g_loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    losses = (tr.disc_loss_value(), tr.gen_loss_value())
+
+    roofline = None
+    if not args.no_roofline:
+        dk = dominant_kernel(args.workload, args.dtype, (128, args.width), args.seq)
+        ops.time_entry_point(dk["name"])
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        avg_ms, launches = ops.timed_durations_ms()
+        ops.time_entry_point(None)
+        # model 1: the timed entry point runs on the 2B batch (D step) and on B (G step): average samples per launch
+        if args.workload == "simnn":
+            samples_per_launch = (2 * args.batch + args.batch) / 2.0
+            achieved = dk["bytes_per_sample"] * samples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": "conv2_fwd_kernel (gdm_simnn_conv2_fwd)", "avg_launch_ms": round(avg_ms, 4),
+                        "launches_timed": launches}
+        else:
+            roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                        "traffic": None, "kernel": "gemm_kernel (all gdm_gemm launches pooled)",
+                        "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if roofline and os.path.exists(tfile):
+            try:
+                roofline["traffic"] = json.load(open(tfile)).get(f"{args.workload}_{args.dtype}")
+            except Exception:
+                pass
+    barrier()
+
+    if rank == 0:
+        total = world * args.batch * args.steps
+        out = {
+            "metric": "GAN training samples/sec (G+D step)", "value": round(total / elapsed, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {
+                "workload": ("SIMNN G/D iteration, synthetic 128x%d spectrogram windows" % args.width
+                             if args.workload == "simnn" else
+                             "MMGAN (G + beat-G + D) iteration, MAESTRO-shaped synthetic (2,128,%d) rolls" % args.seq),
+                "per_gpu_batch": args.batch, "global_batch": args.batch * world, "mode": args.mode,
+                "parallelism": f"dp{world}", "iteration": "1 G fwd, 3 D fwd, 2 D bwd, Adam(D)" if
+                args.workload == "simnn" else "2x(G1,G2) fwd, 3 D fwd, 2 D bwd, Adam(D)",
+            },
+            "final_losses": {"disc": round(losses[0], 6), "gen": round(losses[1], 6)},
+        }
+        if roofline is not None:
+            out["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

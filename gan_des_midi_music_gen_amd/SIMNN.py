@@ -1,0 +1,204 @@
+"""Drop-in surface of model 1 (GAN_DES/SIMNN.py) on MI355X.
+
+Same public names, constructor signatures, state_dict keys and training-loop semantics as the reference module:
+
+    get_noise(n_samples, noise_dim, device='cpu')                 SIMNN.py:37-46
+    weights_init(m)                                               SIMNN.py:49-59
+    Generator(no_of_channels=1, noise_dim=100, gen_dim=32)        SIMNN.py:62-112
+    Discriminator(no_of_channels=1, disc_dim=32)                  SIMNN.py:115-142
+    SimNN(n)                                                      SIMNN.py:145-198 (name + signature only, see class)
+    generate_song(model_folder)                                   SIMNN.py:201-216
+    train(...)  /  python -m gan_des_midi_music_gen_amd.SIMNN     SIMNN.py:234-348 (the __main__ loop)
+
+The module tree holds ordinary ``nn.ConvTranspose2d / nn.BatchNorm2d / nn.Conv2d / nn.Linear`` children purely as
+parameter containers (so ``.apply(weights_init)``, ``state_dict()``, ``load_state_dict(strict=True)`` of the committed
+``gen_100_*.pt`` and any ``torch.optim`` optimizer behave exactly as with the reference); their own ``forward`` is
+never called -- ``forward`` here dispatches to the HIP kernels behind include/gdm.h.
+"""
+import os
+import time
+
+import torch
+from torch import nn
+import torch.nn.init as init
+
+from . import functional as Fn
+from . import synthetic
+
+
+def get_noise(n_samples, noise_dim, device="cpu"):
+    """(n_samples, noise_dim, 1, 1) standard-normal noise on ``device``."""
+    return torch.randn(n_samples, noise_dim, 1, 1, device=device)
+
+
+def weights_init(m):
+    """Conv2d/ConvTranspose2d weight ~ N(0, 0.02); BatchNorm2d weight ~ N(0, 0.02) (as the reference does), bias 0."""
+    if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+        init.normal_(m.weight, mean=0.0, std=0.02)
+    if isinstance(m, nn.BatchNorm2d):
+        init.normal_(m.weight, mean=0.0, std=0.02)
+        init.constant_(m.bias, val=0)
+
+
+class Generator(nn.Module):
+    """noise (B,noise_dim,1,1) -> DES parameter matrix (B,no_of_channels,20,20) in (0,1).
+
+    ConvT(noise->4g,k4) BN ReLU, ConvT(4g->2g,k4,s2,p1) BN ReLU, ConvT(2g->g,k4,s2,p1) BN ReLU, ConvT(g->C,k5), sigmoid.
+    """
+
+    def __init__(self, no_of_channels=1, noise_dim=100, gen_dim=32):
+        super().__init__()
+        g = gen_dim
+        self.conv1 = nn.ConvTranspose2d(noise_dim, g * 4, kernel_size=4, stride=1, padding=0, bias=False)
+        self.conv2 = nn.ConvTranspose2d(g * 4, g * 2, kernel_size=4, stride=2, padding=1, bias=False)
+        self.conv3 = nn.ConvTranspose2d(g * 2, g, kernel_size=4, stride=2, padding=1, bias=False)
+        self.conv4 = nn.ConvTranspose2d(g, no_of_channels, kernel_size=5, stride=1, padding=0, bias=False)
+        self.batch_norm1 = nn.BatchNorm2d(g * 4)
+        self.batch_norm2 = nn.BatchNorm2d(g * 2)
+        self.batch_norm3 = nn.BatchNorm2d(g)
+        self.compute_dtype = None  # None -> functional.get_compute_dtype()
+        self._initialize_weights()
+
+    def _initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.ConvTranspose2d):
+                init.normal_(m.weight, 0.0, 0.02)
+            elif isinstance(m, nn.BatchNorm2d):
+                init.normal_(m.weight, 1.0, 0.02)
+                init.constant_(m.bias, 0)
+
+    def forward(self, input):
+        dt = Fn.get_compute_dtype() if self.compute_dtype is None else Fn._NAMES[self.compute_dtype]
+        bns = (self.batch_norm1, self.batch_norm2, self.batch_norm3)
+        buffers = tuple((bn.running_mean, bn.running_var, bn.num_batches_tracked) for bn in bns)
+        return Fn.SimnnGenFn.apply(input, self.conv1.weight, self.conv2.weight, self.conv3.weight, self.conv4.weight,
+                                   bns[0].weight, bns[0].bias, bns[1].weight, bns[1].bias, bns[2].weight, bns[2].bias,
+                                   buffers, self.training, dt)
+
+
+def disc_feature_hw(input_hw):
+    """(H, W) of the input window -> (H2, W2) of the 32-channel feature map in front of fc1."""
+    h, w = input_hw
+    return ((h + 1) // 2) // 2, ((w + 1) // 2) // 2
+
+
+class Discriminator(nn.Module):
+    """(B, H, W) mel-dB windows -> (B, 1) sigmoid scores.
+
+    Conv(1->16,k2,p1) ReLU Pool2, Conv(16->32,k3,p1) ReLU Pool2, flatten, Linear(->128) ReLU, Linear(->1), sigmoid.
+    ``input_hw`` (keyword-only, default = the reference's hard-wired 128x216 -> fc1.in_features 32*32*54) is the
+    build's one extension: the benchmark config uses 128x256 windows (geometry note).
+    """
+
+    def __init__(self, no_of_channels=1, disc_dim=32, *, input_hw=(128, 216)):
+        super().__init__()
+        self.input_hw = tuple(input_hw)
+        fh, fw = disc_feature_hw(self.input_hw)
+        self.conv1 = nn.Conv2d(1, 16, kernel_size=2, stride=1, padding=1)
+        self.conv2 = nn.Conv2d(16, 32, kernel_size=3, stride=1, padding=1)
+        self.pool = nn.MaxPool2d(kernel_size=2, stride=2, padding=0)
+        self.fc1 = nn.Linear(32 * fh * fw, 128)
+        self.fc2 = nn.Linear(128, 1)
+        self.compute_dtype = None
+
+    def forward(self, input):
+        dt = Fn.get_compute_dtype() if self.compute_dtype is None else Fn._NAMES[self.compute_dtype]
+        return Fn.SimnnDiscFn.apply(input, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                    self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, dt)
+
+
+class SimNN(nn.Module):
+    """Experimental CNN of the reference (SIMNN.py:145-198); never reached by its training loop.
+
+    The reference re-creates ``fc1`` with fresh random weights on every forward (SIMNN.py:161), so it has no
+    reproducible numeric behaviour to match; only the name, constructor and parameter containers are kept
+    ("next").  ``forward`` raises.
+    """
+
+    def __init__(self, n):
+        super().__init__()
+        self.n = n
+        self.conv1 = nn.Conv2d(1, 32, kernel_size=3, stride=1, padding=1)
+        self.conv2 = nn.Conv2d(32, 64, kernel_size=3, stride=1, padding=1)
+        self.fc1 = nn.Linear(64 * 32 * 32, 512)
+        self.fc2 = nn.Linear(512, self.n * self.n + 4 * self.n)
+
+    def forward(self, x):
+        raise NotImplementedError("SimNN is outside the MI355X hot-path scope (dead code in the reference: "
+                                  "GAN_DES/SIMNN.py:145-198 is never called by the training loop)")
+
+    @staticmethod
+    def create_model(n):
+        return SimNN(n)
+
+
+def generate_song(model_folder, device=None, bridge=None):
+    """Load a generator checkpoint (same ``gen_*.pt`` files the reference writes) and emit one DES matrix.
+
+    The reference then renders audio through ``matrix_to_wav`` (SIMNN.py:214-215), which is outside this build's
+    scope; pass ``bridge=callable`` to continue from the (20,20) numpy matrix, otherwise the matrix is returned.
+    """
+    device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+    gen = Generator()
+    gen.load_state_dict(torch.load(model_folder, map_location="cpu", weights_only=True))
+    gen.to(device).eval()
+    with torch.no_grad():
+        adj = gen(get_noise(1, 100, device=device)).squeeze().detach().cpu().numpy()
+    return bridge(adj) if bridge is not None else adj
+
+
+def train(dataloader=None, *, n_epochs=1, batch_size=30, lr=0.00002, betas=(0.5, 0.999), display_step=5, save_step=5,
+          z_dim=100, model_path="models/", input_hw=(128, 216), fake_provider=None, device=None, seed=None,
+          compute_dtype=None, elide_dead_backward=False, max_steps=None, save=True, log=print):
+    """The reference's ``__main__`` training loop (SIMNN.py:234-348) on the fused MI355X step.
+
+    dataloader: iterable of real batches (B,H,W) fp32 (the reference's MaestroDataset/DataLoader); if None, seeded
+        synthetic spectrogram windows are used (``max_steps`` batches, default 10).
+    fake_provider(generated_numpy (B,20,20)) -> (B,H,W) tensor: stands in for the DES/FluidSynth bridge
+        ``matrix_to_wav`` (SIMNN.py:301); if None, seeded synthetic windows are used.
+    Returns (gen, disc, gen_losses, disc_losses).
+    """
+    from .train import SimnnTrainer
+    device = torch.device(device if device is not None else "cuda")
+    if seed is not None:
+        torch.manual_seed(seed)
+    gen = Generator().to(device)
+    disc = Discriminator(input_hw=input_hw).to(device)
+    gen = gen.apply(weights_init)
+    disc = disc.apply(weights_init)
+    trainer = SimnnTrainer(gen, disc, lr=lr, betas=betas, compute_dtype=compute_dtype,
+                           elide_dead_backward=elide_dead_backward)
+    gen_losses, disc_losses = [], []
+    cur_step = 0
+    for epoch in range(n_epochs):
+        if dataloader is None:
+            n = max_steps if max_steps is not None else 10
+            batches = (synthetic.spectrogram_batch(batch_size, input_hw, seed=1234 + i) for i in range(n))
+        else:
+            batches = iter(dataloader)
+        for real in batches:
+            if max_steps is not None and cur_step >= max_steps:
+                break
+            real = real.to(device)
+            cur_batch_size = len(real)
+            noise = get_noise(cur_batch_size, z_dim, device=device)
+            if fake_provider is None:
+                provider = lambda _adj, n=cur_batch_size, s=cur_step: synthetic.spectrogram_batch(  # noqa: E731
+                    n, input_hw, seed=99991 + s)
+            else:
+                provider = fake_provider
+            d_loss, g_loss = trainer.step(real, noise, provider)
+            disc_losses.append(d_loss.item())
+            gen_losses.append(g_loss.item())
+            if cur_step % display_step == 0 and cur_step > 0:
+                log(f"Epoch:{epoch} Step {cur_step}: Generator loss: {sum(gen_losses) / len(gen_losses)}, "
+                    f"discriminator loss: {sum(disc_losses) / len(disc_losses)}")
+            if save and cur_step % save_step == 0 and cur_step > 0:
+                os.makedirs(model_path, exist_ok=True)
+                torch.save(gen.state_dict(), os.path.join(model_path, f"gen_{cur_step}_{time.time()}.pt"))
+            cur_step += 1
+    return gen, disc, gen_losses, disc_losses
+
+
+if __name__ == "__main__":
+    train()

@@ -8,7 +8,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------ BCE with logits
 // mean_i( max(x,0) - x*y + log1p(exp(-|x|)) ); nn.BCEWithLogitsLoss() at SIMNN.py:257 / network_tests.py:248.
 __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ x, float target, int n, float gscale,
-                                                   float* __restrict__ loss, float* __restrict__ dx, int fuse_sig) {
+                                                   float* __restrict__ loss, float* __restrict__ dx, int fuse_sig,
+                                                   int accumulate) {
   __shared__ float red[1024];
   const int t = threadIdx.x;
   float s = 0.f;
@@ -27,23 +28,24 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ x, 
     if (t < o) red[t] += red[t + o];
     __syncthreads();
   }
-  if (t == 0) loss[0] = red[0] / (float)n;
+  if (t == 0) loss[0] = (accumulate ? loss[0] : 0.f) + red[0] / (float)n;
 }
 
 // ------------------------------------------------------------------------------------------------------------ Adam
 // torch.optim.Adam single-tensor update (lerp form of exp_avg, sqrt/bias-correction/eps order as torch).
+template <bool VEC>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                    float w1, float beta2, float one_minus_b2, float step_size,
-                                                   float bc2_sqrt, float eps) {
+                                                   float bc2_sqrt, float eps, float gscale) {
   const int64_t stride = (int64_t)gridDim.x * 256 * 4;
   for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
-    if (i + 3 < n) {
+    if (VEC && i + 3 < n) {
       f32x4 pp = *(const f32x4*)(p + i), gg = *(const f32x4*)(g + i), mm = *(const f32x4*)(m + i),
             vv = *(const f32x4*)(v + i);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float gj = gg[j];
+        const float gj = gg[j] * gscale;
         const float mj = (w1 < 0.5f) ? mm[j] + w1 * (gj - mm[j]) : gj - (gj - mm[j]) * (1.f - w1);
         const float vj = vv[j] * beta2 + one_minus_b2 * gj * gj;
         const float denom = sqrtf(vj) / bc2_sqrt + eps;
@@ -55,8 +57,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       *(f32x4*)(m + i) = mm;
       *(f32x4*)(v + i) = vv;
     } else {
-      for (int64_t k = i; k < n; ++k) {
-        const float gj = g[k];
+      for (int64_t k = i; k < n && k < i + 4; ++k) {
+        const float gj = g[k] * gscale;
         const float mj = (w1 < 0.5f) ? m[k] + w1 * (gj - m[k]) : gj - (gj - m[k]) * (1.f - w1);
         const float vj = v[k] * beta2 + one_minus_b2 * gj * gj;
         const float denom = sqrtf(vj) / bc2_sqrt + eps;
@@ -276,21 +278,20 @@ inline unsigned grid_for(int64_t total) {
 }  // namespace
 
 extern "C" int gdm_bce_with_logits(const float* x, float target, int n, float grad_scale, float* loss, float* dx,
-                                   int fuse_sigmoid_backward, void* stream) {
+                                   int fuse_sigmoid_backward, int accumulate_loss, void* stream) {
   GDM_REQUIRE(x && loss, "gdm_bce_with_logits: null pointer");
   GDM_REQUIRE(n > 0 && n <= 65536, "gdm_bce_with_logits: n=%d out of range (1..65536)", n);
   hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, target, n, grad_scale, loss, dx,
-                     fuse_sigmoid_backward);
+                     fuse_sigmoid_backward, accumulate_loss);
   GDM_LAUNCH_OK("gdm_bce_with_logits");
   return GDM_OK;
 }
 
 extern "C" int gdm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
-                             float beta2, float eps, void* stream) {
+                             float beta2, float eps, float grad_scale, void* stream) {
   GDM_REQUIRE(p && g && m && v, "gdm_adam_step: null pointer");
   GDM_REQUIRE(n > 0 && step >= 1, "gdm_adam_step: bad n=%lld or step=%d", (long long)n, step);
-  GDM_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
-              "gdm_adam_step: buffers must be 16-byte aligned");
+  const bool aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr / bc1);
@@ -298,8 +299,12 @@ extern "C" int gdm_adam_step(float* p, const float* g, float* m, float* v, int64
   int64_t blocks = (n / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
-                     1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2_sqrt, eps);
+  if (aligned)
+    hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2_sqrt, eps, grad_scale);
+  else
+    hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2_sqrt, eps, grad_scale);
   GDM_LAUNCH_OK("gdm_adam_step");
   return GDM_OK;
 }

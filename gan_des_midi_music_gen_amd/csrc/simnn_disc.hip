@@ -144,12 +144,14 @@ __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restri
 }
 
 __global__ __launch_bounds__(128) void conv1_bwd_weight_final(const float* __restrict__ slabs, int nslabs,
-                                                              float* __restrict__ dw, float* __restrict__ db) {
+                                                              float* __restrict__ dw, float* __restrict__ db,
+                                                              int accumulate) {
   const int i = threadIdx.x;
   if (i >= 80) return;
   float s = 0.f;
   for (int k = 0; k < nslabs; ++k) s += slabs[(int64_t)k * 80 + i];
-  if (i < 64) dw[i] = s; else db[i - 64] = s;
+  float* dst = i < 64 ? dw + i : db + (i - 64);
+  *dst = accumulate ? *dst + s : s;
 }
 
 // =====================================================================================================================
@@ -619,8 +621,8 @@ extern "C" size_t gdm_simnn_conv1_bwd_weight_workspace_bytes(int B, int H, int W
 }
 
 extern "C" int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1, const float* x, int B, int H, int W,
-                                          float* dw, float* db, int dtype, void* workspace, size_t workspace_bytes,
-                                          void* stream) {
+                                          float* dw, float* db, int dtype, int accumulate, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
   GDM_REQUIRE(dp1 && code1 && x && dw && db, "gdm_simnn_conv1_bwd_weight: null pointer");
   GDM_REQUIRE(B > 0 && H >= 1 && W >= 1 && gdm_dtype_ok(dtype), "gdm_simnn_conv1_bwd_weight: bad arguments");
   if (!workspace || workspace_bytes < gdm_simnn_conv1_bwd_weight_workspace_bytes(B, H, W)) {
@@ -632,7 +634,8 @@ extern "C" int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_bwd_weight_kernel<T>, dim3(nslabs), dim3(256), 0, s, (const T*)dp1, code1,
                                        x, B, H, W, H1, W1, (float*)workspace));
-  hipLaunchKernelGGL(conv1_bwd_weight_final, dim3(1), dim3(128), 0, s, (const float*)workspace, nslabs, dw, db);
+  hipLaunchKernelGGL(conv1_bwd_weight_final, dim3(1), dim3(128), 0, s, (const float*)workspace, nslabs, dw, db,
+                     accumulate);
   GDM_LAUNCH_OK("gdm_simnn_conv1_bwd_weight");
   return GDM_OK;
 }

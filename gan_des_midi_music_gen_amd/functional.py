@@ -1,0 +1,364 @@
+"""Network-level forward/backward composites over the C-ABI kernels, and their autograd.Function shells.
+
+Each composite is a fixed sequence of ``ops.*`` calls (all enqueued on the current HIP stream, no host sync), returns
+what backward needs as a plain tuple, and is used both by the nn.Module classes (through the autograd Functions
+below) and by the fused training steps in ``train.py`` (directly, without autograd).
+
+compute dtype: ``F32`` = exact-fp32 parity mode, ``BF16`` = bf16 activations/MFMA with fp32 accumulation and fp32
+parameters.  ``set_compute_dtype`` / ``compute_dtype`` select the process-wide default used by the modules.
+"""
+import contextlib
+
+import torch
+
+from . import ops
+from .ops import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, BF16, F32
+
+_DEFAULT = {"dtype": F32}
+_NAMES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, F32: F32, BF16: BF16}
+
+
+def set_compute_dtype(name):
+    _DEFAULT["dtype"] = _NAMES[name]
+
+
+def get_compute_dtype():
+    return _DEFAULT["dtype"]
+
+
+@contextlib.contextmanager
+def compute_dtype(name):
+    old = _DEFAULT["dtype"]
+    _DEFAULT["dtype"] = _NAMES[name]
+    try:
+        yield
+    finally:
+        _DEFAULT["dtype"] = old
+
+
+def _f32c(t):
+    return t.detach().contiguous() if t.dtype == torch.float32 else t.detach().float().contiguous()
+
+
+# ======================================================================================================================
+# Model 1 discriminator (GAN_DES/SIMNN.py:115-142)
+# ======================================================================================================================
+def simnn_disc_forward(x, w1, b1, w2, b2, wf1, bf1, wf2, bf2, dt):
+    """x (B,H,W) fp32 -> p (B,1) fp32 = sigmoid(fc2(relu(fc1(flatten(trunk(x)))))); returns (p, saved)."""
+    x = _f32c(x)
+    p1, code1 = ops.simnn_conv1_fwd(x, w1, b1, dt)
+    p2, code2 = ops.simnn_conv2_fwd(p1, w2, b2)
+    b = x.shape[0]
+    flat = p2.view(b, -1)
+    if flat.shape[1] != wf1.shape[1]:
+        raise ValueError(f"Discriminator.fc1 expects {wf1.shape[1]} features but the {tuple(x.shape[1:])} input gives "
+                         f"{flat.shape[1]} (construct Discriminator(input_hw=...) for this geometry)")
+    h1 = ops.gemm(flat, wf1.t(), bias_n=bf1, act=ACT_RELU, compute=dt)
+    p = ops.gemm(h1, wf2.t(), bias_n=bf2, act=ACT_SIGMOID, compute=dt)
+    return p, (x, p1, code1, flat, code2, h1, p)
+
+
+def simnn_disc_backward(saved, dz, w2, wf1, wf2, dt):
+    """dz (B,1) fp32 = d loss / d (pre-sigmoid logit).  Returns grads in parameter order (w1,b1,w2,b2,wf1,bf1,wf2,bf2)."""
+    x, p1, code1, flat, code2, h1, _p = saved
+    b = x.shape[0]
+    dz = dz.reshape(b, 1).contiguous()
+    dwf2 = ops.gemm(dz.t(), h1, compute=dt)                                   # (1,128)
+    dbf2 = ops.colsum(dz)
+    dh1 = ops.gemm(dz, wf2, compute=dt)                                       # (B,128)
+    dh1 = ops.act_bwd(dh1, h1, act=ACT_RELU)
+    dwf1 = ops.gemm(dh1.t(), flat, compute=dt)                                # (128,K)
+    dbf1 = ops.colsum(dh1)
+    dflat = ops.gemm(dh1, wf1, compute=dt, out_dtype=dt)                      # (B,K) in the activation dtype
+    h1s, w1s = p1.shape[1], p1.shape[2]
+    dp2 = dflat.view(b, 32, h1s // 2, w1s // 2)
+    dw2, db2 = ops.simnn_conv2_bwd_weight(dp2, code2, p1)
+    dp1 = ops.simnn_conv2_bwd_data(dp2, code2, w2, h1s, w1s)
+    dw1, db1 = ops.simnn_conv1_bwd_weight(dp1, code1, x)
+    return dw1, db1, dw2, db2, dwf1, dbf1, dwf2, dbf2
+
+
+class SimnnDiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, wf1, bf1, wf2, bf2, dt):
+        p, saved = simnn_disc_forward(x, w1.detach(), b1.detach(), w2.detach(), b2.detach(), wf1.detach(),
+                                      bf1.detach(), wf2.detach(), bf2.detach(), dt)
+        ctx.saved = saved
+        ctx.weights = (w2.detach(), wf1.detach(), wf2.detach())
+        ctx.dt = dt
+        ctx.x_needs_grad = x.requires_grad
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        if ctx.x_needs_grad:
+            raise NotImplementedError("gradient w.r.t. the discriminator's spectrogram input is not on the reference's "
+                                      "path (its inputs are data or detached bridge outputs, SIMNN.py:283,299-306)")
+        p = ctx.saved[-1]
+        dz = ops.act_bwd(dp.contiguous().float(), p, act=ACT_SIGMOID)
+        w2, wf1, wf2 = ctx.weights
+        grads = simnn_disc_backward(ctx.saved, dz, w2, wf1, wf2, ctx.dt)
+        return (None, *grads, None)
+
+
+# ======================================================================================================================
+# ConvTranspose2d / Conv2d as GEMM + patch lowering (channels-last activations)
+# ======================================================================================================================
+def convT_forward(x2d, w, b, ih, iw, stride, pad, dt):
+    """x2d (B*IH*IW, Cin) -> y (B*OH*OW, Cout) fp32 channels-last; w is torch's (Cin, Cout, KH, KW)."""
+    cin, cout, kh, kw = w.shape
+    oh = (ih - 1) * stride - 2 * pad + kh
+    ow = (iw - 1) * stride - 2 * pad + kw
+    cols = ops.gemm(x2d, w.view(cin, cout * kh * kw), compute=dt, out_dtype=F32)
+    y = ops.col2im(cols, b=b, h=oh, w=ow, c=cout, kh=kh, kw=kw, stride=stride, pad=pad, oh=ih, ow=iw, out_dtype=F32)
+    return y.view(b * oh * ow, cout), oh, ow
+
+
+def convT_backward(dy2d, x2d, w, b, ih, iw, oh, ow, stride, pad, dt, need_dx=True):
+    """dy2d (B*OH*OW, Cout) fp32 -> (dx2d (B*IH*IW, Cin) fp32 or None, dw like w)."""
+    cin, cout, kh, kw = w.shape
+    dcols, oh2, ow2 = ops.im2col(dy2d, planar=False, b=b, h=oh, w=ow, c=cout, kh=kh, kw=kw, stride=stride, pad=pad,
+                                 out_dtype=F32)
+    # im2col's output grid for a transposed conv is the transposed conv's INPUT grid
+    if (oh2, ow2) != (ih, iw):
+        raise AssertionError(f"transposed-conv geometry mismatch {(oh2, ow2)} vs {(ih, iw)}")
+    dw = ops.gemm(x2d.t(), dcols, compute=dt).view(cin, cout, kh, kw)
+    dx = ops.gemm(dcols, w.view(cin, cout * kh * kw).t(), compute=dt) if need_dx else None
+    return dx, dw
+
+
+# ======================================================================================================================
+# Model 1 generator (GAN_DES/SIMNN.py:62-112)
+# ======================================================================================================================
+_G_GEOM = ((1, 0), (2, 1), (2, 1), (1, 0))   # (stride, padding) of conv1..conv4
+
+
+def simnn_gen_forward(noise, ws, bns, training, dt):
+    """noise (B,100,1,1); ws = 4 ConvTranspose2d weights; bns = 3 x (gamma, beta, rmean, rvar, nbt).
+
+    Returns (out (B,1,20,20) fp32, saved).  Activations are channels-last 2-D matrices (B*H*W, C).
+    """
+    b = noise.shape[0]
+    x = _f32c(noise).view(b, -1)
+    ih = iw = 1
+    saved = []
+    for li in range(4):
+        stride, pad = _G_GEOM[li]
+        w = ws[li]
+        y, oh, ow = convT_forward(x, w, b, ih, iw, stride, pad, dt)
+        if li < 3:
+            gamma, beta, rm, rv, nbt = bns[li]
+            out, mean, invstd = ops.bn_act_fwd(y, gamma, beta, rm, rv, nbt, act=ACT_RELU, out_dtype=F32,
+                                               training=training)
+            saved.append((x, y, out, mean, invstd, ih, iw, oh, ow))
+            x = out
+        else:
+            out = ops.bias_act_fwd(y, None, act=ACT_SIGMOID)
+            saved.append((x, y, out, None, None, ih, iw, oh, ow))
+        ih, iw = oh, ow
+    c_out = ws[3].shape[1]
+    # channels-last (B,20,20,C) -> (B,C,20,20); for the reference's C == 1 this is a free view
+    img = out.view(b, ih, iw, c_out)
+    img = img.view(b, 1, ih, iw) if c_out == 1 else ops.permute_pc(out, b, ih * iw, c_out).view(b, c_out, ih, iw)
+    return img, saved
+
+
+def simnn_gen_backward(saved, dimg, ws, bns, dt, need_dnoise=True):
+    """dimg (B,C,20,20) -> (dnoise or None, [dw1..dw4], [(dgamma, dbeta) x3])."""
+    b = dimg.shape[0]
+    c_out = ws[3].shape[1]
+    dimg = _f32c(dimg)
+    d = dimg.view(-1, 1) if c_out == 1 else ops.permute_pc(dimg, b, c_out, dimg.shape[2] * dimg.shape[3]).view(-1, c_out)
+    dws, dbn = [None] * 4, [None] * 3
+    for li in (3, 2, 1, 0):
+        x, y, out, mean, invstd, ih, iw, oh, ow = saved[li]
+        stride, pad = _G_GEOM[li]
+        if li == 3:
+            dy = ops.act_bwd(d.contiguous(), out, act=ACT_SIGMOID)
+        else:
+            gamma = bns[li][0]
+            dy, dgamma, dbeta = ops.bn_act_bwd(d.contiguous(), out, y, gamma, mean, invstd, act=ACT_RELU)
+            dbn[li] = (dgamma, dbeta)
+        d, dws[li] = convT_backward(dy, x, ws[li], b, ih, iw, oh, ow, stride, pad, dt,
+                                    need_dx=(li > 0 or need_dnoise))
+    dnoise = d.view(b, -1, 1, 1) if d is not None else None
+    return dnoise, dws, dbn
+
+
+class SimnnGenFn(torch.autograd.Function):
+    """args: noise, w1..w4, (gamma,beta) x3, then non-differentiable: buffers tuple, training flag, dtype."""
+
+    @staticmethod
+    def forward(ctx, noise, w1, w2, w3, w4, g1, be1, g2, be2, g3, be3, buffers, training, dt):
+        ws = [w.detach() for w in (w1, w2, w3, w4)]
+        bns = [(g.detach(), be.detach(), *buf) for (g, be), buf in zip(((g1, be1), (g2, be2), (g3, be3)), buffers)]
+        img, saved = simnn_gen_forward(noise, ws, bns, training, dt)
+        if not training:
+            ctx.eval_mode = True
+        ctx.saved, ctx.ws, ctx.bns, ctx.dt = saved, ws, bns, dt
+        ctx.need_dnoise = noise.requires_grad
+        ctx.training = training
+        return img
+
+    @staticmethod
+    def backward(ctx, dimg):
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not on the reference's path")
+        dnoise, dws, dbn = simnn_gen_backward(ctx.saved, dimg, ctx.ws, ctx.bns, ctx.dt, ctx.need_dnoise)
+        return (dnoise, *dws, dbn[0][0], dbn[0][1], dbn[1][0], dbn[1][1], dbn[2][0], dbn[2][1], None, None, None)
+
+
+# ======================================================================================================================
+# Model 2 generators: 4 x [Linear -> BatchNorm1d -> Sigmoid] (MMGAN_MIDI_DES/network_tests.py:67-80, 102-115)
+# ======================================================================================================================
+def mlp_bn_sigmoid_forward(x, layers, training, dt):
+    """layers: list of (W (out,in), b, gamma, beta, rmean, rvar, nbt).  Returns (out fp32, saved)."""
+    saved = []
+    x = _f32c(x)
+    for (w, bias, gamma, beta, rm, rv, nbt) in layers:
+        y = ops.gemm(x, w.t(), bias_n=bias, compute=dt)
+        out, mean, invstd = ops.bn_act_fwd(y, gamma, beta, rm, rv, nbt, act=ACT_SIGMOID, out_dtype=F32,
+                                           training=training)
+        saved.append((x, y, out, mean, invstd))
+        x = out
+    return x, saved
+
+
+def mlp_bn_sigmoid_backward(saved, dout, layers, dt, need_dx=True):
+    """Returns (dx or None, [(dW, db, dgamma, dbeta)] per layer)."""
+    grads = [None] * len(layers)
+    d = _f32c(dout)
+    for li in range(len(layers) - 1, -1, -1):
+        x, y, out, mean, invstd = saved[li]
+        w, gamma = layers[li][0], layers[li][2]
+        dy, dgamma, dbeta = ops.bn_act_bwd(d, out, y, gamma, mean, invstd, act=ACT_SIGMOID)
+        dw = ops.gemm(dy.t(), x, compute=dt)
+        db = ops.colsum(dy)
+        grads[li] = (dw, db, dgamma, dbeta)
+        d = ops.gemm(dy, w, compute=dt) if (li > 0 or need_dx) else None
+    return d, grads
+
+
+class MlpBnSigmoidFn(torch.autograd.Function):
+    """args: x, then per layer (W, b, gamma, beta) x L, then buffers tuple ((rm, rv, nbt) x L), training, dtype."""
+
+    @staticmethod
+    def forward(ctx, x, *rest):
+        buffers, training, dt = rest[-3], rest[-2], rest[-1]
+        params = rest[:-3]
+        n_layers = len(params) // 4
+        layers = [tuple(p.detach() for p in params[4 * i:4 * i + 4]) + tuple(buffers[i]) for i in range(n_layers)]
+        out, saved = mlp_bn_sigmoid_forward(x, layers, training, dt)
+        ctx.saved, ctx.layers, ctx.dt, ctx.training = saved, layers, dt, training
+        ctx.need_dx = x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not on the reference's path")
+        dx, grads = mlp_bn_sigmoid_backward(ctx.saved, dout, ctx.layers, ctx.dt, ctx.need_dx)
+        flat = [g for layer in grads for g in layer]
+        return (dx, *flat, None, None, None)
+
+
+# ======================================================================================================================
+# Model 2 CNN discriminator (MMGAN_MIDI_DES/network_tests.py:147-160)
+# ======================================================================================================================
+def dcnn_forward(image, w1, b1, w2, b2, wf, bf, dt):
+    """image (B,2,H,T) fp32 (any strides) -> logits (B,1) fp32; returns (logits, saved)."""
+    b, c, h, t = image.shape
+    img = _f32c(image)
+    co1, co2 = w1.shape[0], w2.shape[0]
+    cols1, oh1, ow1 = ops.im2col(img, planar=True, b=b, h=h, w=t, c=c, kh=4, kw=4, stride=2, pad=1, out_dtype=dt)
+    a1 = ops.gemm(cols1, w1.view(co1, -1).t(), bias_n=b1, act=ACT_LEAKY, slope=0.2, compute=dt, out_dtype=dt)
+    cols2, oh2, ow2 = ops.im2col(a1, planar=False, b=b, h=oh1, w=ow1, c=co1, kh=4, kw=4, stride=2, pad=1,
+                                 out_dtype=dt)
+    a2 = ops.gemm(cols2, w2.view(co2, -1).t(), bias_n=b2, act=ACT_LEAKY, slope=0.2, compute=dt, out_dtype=dt)
+    flat = ops.permute_pc(a2, b, oh2 * ow2, co2).view(b, -1)          # channel-major flatten (x.view(len(x), -1))
+    if flat.shape[1] != wf.shape[1]:
+        raise ValueError(f"DiscriminatorCNN.fc expects {wf.shape[1]} features, the {(c, h, t)} roll gives "
+                         f"{flat.shape[1]}")
+    logits = ops.gemm(flat, wf.t(), bias_n=bf, compute=dt)
+    return logits, (cols1, a1, cols2, a2, flat, (b, oh1, ow1, oh2, ow2, co1, co2))
+
+
+def dcnn_backward(saved, dlogits, w2, wf, dt):
+    """dlogits (B,1) fp32.  Returns (dw1, db1, dw2, db2, dwf, dbf)."""
+    cols1, a1, cols2, a2, flat, (b, oh1, ow1, oh2, ow2, co1, co2) = saved
+    dl = _f32c(dlogits).view(b, 1)
+    dwf = ops.gemm(dl.t(), flat, compute=dt)
+    dbf = ops.colsum(dl)
+    dflat = ops.gemm(dl, wf, compute=dt, out_dtype=dt)                              # (B, co2*P2) channel-major
+    da2 = ops.permute_pc(dflat, b, co2, oh2 * ow2).view(b * oh2 * ow2, co2)        # back to channels-last
+    dy2 = ops.act_bwd(da2, a2, act=ACT_LEAKY, slope=0.2)
+    dw2 = ops.gemm(dy2.t(), cols2, compute=dt).view(w2.shape)
+    db2 = ops.colsum(dy2)
+    dcols2 = ops.gemm(dy2, w2.view(co2, -1), compute=dt, out_dtype=F32)
+    da1 = ops.col2im(dcols2, b=b, h=oh1, w=ow1, c=co1, kh=4, kw=4, stride=2, pad=1, oh=oh2, ow=ow2,
+                     out_dtype=dt).view(b * oh1 * ow1, co1)
+    dy1 = ops.act_bwd(da1, a1, act=ACT_LEAKY, slope=0.2)
+    dw1 = ops.gemm(dy1.t(), cols1, compute=dt).view(co1, -1, 4, 4)
+    db1 = ops.colsum(dy1)
+    return dw1, db1, dw2, db2, dwf, dbf
+
+
+class DcnnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, w1, b1, w2, b2, wf, bf, dt):
+        logits, saved = dcnn_forward(image, w1.detach(), b1.detach(), w2.detach(), b2.detach(), wf.detach(),
+                                     bf.detach(), dt)
+        ctx.saved, ctx.dt = saved, dt
+        ctx.weights = (w2.detach(), wf.detach())
+        ctx.x_needs_grad = image.requires_grad
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        if ctx.x_needs_grad:
+            raise NotImplementedError("gradient w.r.t. the piano-roll input is not on the reference's path "
+                                      "(bridge outputs carry no graph, network_tests.py:189-193)")
+        w2, wf = ctx.weights
+        grads = dcnn_backward(ctx.saved, dlogits, w2, wf, ctx.dt)
+        dw1 = grads[0].view(ctx.saved[-1][5], -1, 4, 4)
+        return (None, dw1, *grads[1:], None)
+
+
+# ======================================================================================================================
+# Model 2 MLP discriminator: 3 x [Linear -> LeakyReLU(0.2)] (network_tests.py:126-144); API surface
+# ======================================================================================================================
+def mlp_leaky_forward(x, layers, dt):
+    saved = []
+    x = _f32c(x)
+    for (w, bias) in layers:
+        out = ops.gemm(x, w.t(), bias_n=bias, act=ACT_LEAKY, slope=0.2, compute=dt)
+        saved.append((x, out))
+        x = out
+    return x, saved
+
+
+def mlp_leaky_backward(saved, dout, layers, dt, need_dx=False):
+    grads = [None] * len(layers)
+    d = _f32c(dout)
+    for li in range(len(layers) - 1, -1, -1):
+        x, out = saved[li]
+        dy = ops.act_bwd(d, out, act=ACT_LEAKY, slope=0.2)
+        grads[li] = (ops.gemm(dy.t(), x, compute=dt), ops.colsum(dy))
+        d = ops.gemm(dy, layers[li][0], compute=dt) if (li > 0 or need_dx) else None
+    return d, grads
+
+
+class MlpLeakyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, *rest):
+        dt = rest[-1]
+        params = rest[:-1]
+        layers = [(params[2 * i].detach(), params[2 * i + 1].detach()) for i in range(len(params) // 2)]
+        out, saved = mlp_leaky_forward(x, layers, dt)
+        ctx.saved, ctx.layers, ctx.dt, ctx.need_dx = saved, layers, dt, x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx, grads = mlp_leaky_backward(ctx.saved, dout, ctx.layers, ctx.dt, ctx.need_dx)
+        return (dx, *[g for layer in grads for g in layer], None)

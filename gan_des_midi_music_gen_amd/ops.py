@@ -40,6 +40,38 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional per-entry-point device timing (bench.py's roofline leg): while ``_TIMED["name"]`` names a C-ABI function,
+# every call of it is bracketed by two HIP events recorded on the stream the kernel is launched on.
+_TIMED = {"name": None, "events": []}
+
+
+def time_entry_point(name):
+    """Start (name) / stop (None) collecting (start, end) event pairs for one C-ABI entry point."""
+    _TIMED["name"] = name
+    _TIMED["events"] = []
+
+
+def timed_durations_ms():
+    """Average and count of the collected launches (call after a device synchronize)."""
+    ev = _TIMED["events"]
+    if not ev:
+        return 0.0, 0
+    return sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)
+
+
+def _call(name, *args):
+    fn = getattr(_lib.load(), name)
+    if _TIMED["name"] == name:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        _TIMED["events"].append((a, b))
+    else:
+        rc = fn(*args)
+    check(rc, name)
+
+
 _ws_cache = {}
 
 
@@ -79,30 +111,33 @@ def gemm(a, b, *, bias_n=None, bias_m=None, act=ACT_NONE, slope=0.0, out_dtype=N
         ws_bytes = split_k * m * n * 4
         ws = workspace(ws_bytes, a.device)
     lib = _lib.load()
-    check(lib.gdm_gemm(_p(a), gdm_dtype(a), a.stride(0), a.stride(1), _p(b), gdm_dtype(b), b.stride(0), b.stride(1),
+    _call("gdm_gemm", _p(a), gdm_dtype(a), a.stride(0), a.stride(1), _p(b), gdm_dtype(b), b.stride(0), b.stride(1),
                        _p(out), gdm_dtype(out), out.stride(0), out.stride(1), m, n, k, _p(bias_n), _p(bias_m), act,
-                       float(slope), compute, split_k, _p(ws), ws_bytes, _stream()), "gdm_gemm")
+                       float(slope), compute, split_k, _p(ws), ws_bytes, _stream())
     return out
 
 
-def bce_with_logits(x, target, *, grad_scale=1.0, want_grad=True, fuse_sigmoid_backward=False, loss_out=None):
+def bce_with_logits(x, target, *, grad_scale=1.0, want_grad=True, fuse_sigmoid_backward=False, loss_out=None,
+                    accumulate_loss=False, dx_out=None):
     """Returns (loss (1,) fp32 tensor, dx or None).  x: (n,) fp32 contiguous."""
-    _need_gpu(x)
+    _need_gpu(x, loss_out, dx_out)
     x = x.reshape(-1)
     assert x.dtype == torch.float32 and x.is_contiguous()
     loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=x.device)
-    dx = torch.empty_like(x) if want_grad else None
-    check(_lib.load().gdm_bce_with_logits(_p(x), float(target), x.numel(), float(grad_scale), _p(loss), _p(dx),
-                                           1 if fuse_sigmoid_backward else 0, _stream()), "gdm_bce_with_logits")
+    dx = dx_out if dx_out is not None else (torch.empty_like(x) if want_grad else None)
+    if dx is not None:
+        assert dx.is_contiguous() and dx.numel() == x.numel() and dx.dtype == torch.float32
+    _call("gdm_bce_with_logits", _p(x), float(target), x.numel(), float(grad_scale), _p(loss), _p(dx),
+                                           1 if fuse_sigmoid_backward else 0, 1 if accumulate_loss else 0, _stream())
     return loss, dx
 
 
-def adam_step(p, g, m, v, step, lr, beta1, beta2, eps):
+def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, grad_scale=1.0):
     _need_gpu(p, g, m, v)
     for t in (p, g, m, v):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p.numel()
-    check(_lib.load().gdm_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), int(step), float(lr), float(beta1),
-                                    float(beta2), float(eps), _stream()), "gdm_adam_step")
+    _call("gdm_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), int(step), float(lr), float(beta1),
+                                    float(beta2), float(eps), float(grad_scale), _stream())
 
 
 def bn_act_fwd(y, gamma, beta, running_mean, running_var, nbt, *, act, out_dtype=F32, training=True, momentum=0.1,
@@ -117,9 +152,9 @@ def bn_act_fwd(y, gamma, beta, running_mean, running_var, nbt, *, act, out_dtype
     lib = _lib.load()
     nb = lib.gdm_bn_workspace_bytes(rows, c)
     ws = workspace(nb, y.device)
-    check(lib.gdm_bn_act_fwd(_p(y), rows, c, _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(nbt),
+    _call("gdm_bn_act_fwd", _p(y), rows, c, _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(nbt),
                              float(momentum), float(eps), act, _p(out), out_dtype, _p(mean), _p(invstd),
-                             1 if training else 0, _p(ws), nb, _stream()), "gdm_bn_act_fwd")
+                             1 if training else 0, _p(ws), nb, _stream())
     return out, mean, invstd
 
 
@@ -133,8 +168,8 @@ def bn_act_bwd(dout, out, y, gamma, mean, invstd, *, act):
     lib = _lib.load()
     nb = lib.gdm_bn_workspace_bytes(rows, c)
     ws = workspace(nb, y.device)
-    check(lib.gdm_bn_act_bwd(_p(dout), _p(out), gdm_dtype(out), _p(y), rows, c, _p(gamma), _p(mean), _p(invstd), act,
-                             _p(dy), _p(dgamma), _p(dbeta), _p(ws), nb, _stream()), "gdm_bn_act_bwd")
+    _call("gdm_bn_act_bwd", _p(dout), _p(out), gdm_dtype(out), _p(y), rows, c, _p(gamma), _p(mean), _p(invstd), act,
+                             _p(dy), _p(dgamma), _p(dbeta), _p(ws), nb, _stream())
     return dy, dgamma, dbeta
 
 
@@ -142,8 +177,8 @@ def bias_act_fwd(x, bias, *, act, slope=0.0, out_dtype=F32):
     _need_gpu(x, bias)
     assert x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous()
     out = torch.empty(x.shape, dtype=_TORCH_DT[out_dtype], device=x.device)
-    check(_lib.load().gdm_bias_act_fwd(_p(x), _p(bias), x.shape[0], x.shape[1], act, float(slope), _p(out), out_dtype,
-                                       _stream()), "gdm_bias_act_fwd")
+    _call("gdm_bias_act_fwd", _p(x), _p(bias), x.shape[0], x.shape[1], act, float(slope), _p(out), out_dtype,
+                                       _stream())
     return out
 
 
@@ -151,19 +186,21 @@ def act_bwd(dout, out, *, act, slope=0.0):
     _need_gpu(dout, out)
     assert dout.dtype == out.dtype and dout.is_contiguous() and out.is_contiguous() and dout.numel() == out.numel()
     dx = torch.empty_like(dout)
-    check(_lib.load().gdm_act_bwd(_p(dout), _p(out), gdm_dtype(out), out.numel(), act, float(slope), _p(dx),
-                                  _stream()), "gdm_act_bwd")
+    _call("gdm_act_bwd", _p(dout), _p(out), gdm_dtype(out), out.numel(), act, float(slope), _p(dx),
+                                  _stream())
     return dx
 
 
-def colsum(x):
-    _need_gpu(x)
+def colsum(x, out=None):
+    _need_gpu(x, out)
     assert x.dim() == 2 and x.is_contiguous()
     rows, c = x.shape
-    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(c, dtype=torch.float32, device=x.device)
+    assert out.numel() == c and out.is_contiguous() and out.dtype == torch.float32
     nb = ((rows + 63) // 64 + 1) * c * 4
     ws = workspace(nb, x.device)
-    check(_lib.load().gdm_colsum(_p(x), gdm_dtype(x), rows, c, _p(out), _p(ws), nb, _stream()), "gdm_colsum")
+    _call("gdm_colsum", _p(x), gdm_dtype(x), rows, c, _p(out), _p(ws), nb, _stream())
     return out
 
 
@@ -171,20 +208,25 @@ def cast(x, dt):
     _need_gpu(x)
     x = x.contiguous()
     out = torch.empty(x.shape, dtype=_TORCH_DT[dt], device=x.device)
-    check(_lib.load().gdm_cast(_p(x), gdm_dtype(x), _p(out), dt, x.numel(), _stream()), "gdm_cast")
+    _call("gdm_cast", _p(x), gdm_dtype(x), _p(out), dt, x.numel(), _stream())
     return out
 
 
 # ------------------------------------------------------------------------------------------ model 1 conv trunk
-def simnn_conv1_fwd(x, w, bias, dt):
+def simnn_conv1_fwd(x, w, bias, dt, out=None):
+    """out = (p1, code1) preallocated (e.g. halves of a 2B batch buffer) or None."""
     _need_gpu(x, w, bias)
     assert x.dim() == 3 and x.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()
     b, h, wd = x.shape
     h1, w1 = (h + 1) // 2, (wd + 1) // 2
-    p1 = torch.empty((b, h1, w1, 16), dtype=_TORCH_DT[dt], device=x.device)
-    code1 = torch.empty((b, h1, w1), dtype=torch.int64, device=x.device)
-    check(_lib.load().gdm_simnn_conv1_fwd(_p(x), _p(w), _p(bias), b, h, wd, _p(p1), _p(code1), dt, _stream()),
-          "gdm_simnn_conv1_fwd")
+    if out is not None:
+        p1, code1 = out
+        assert p1.shape == (b, h1, w1, 16) and p1.is_contiguous() and p1.dtype == _TORCH_DT[dt]
+        assert code1.shape == (b, h1, w1) and code1.is_contiguous() and code1.dtype == torch.int64
+    else:
+        p1 = torch.empty((b, h1, w1, 16), dtype=_TORCH_DT[dt], device=x.device)
+        code1 = torch.empty((b, h1, w1), dtype=torch.int64, device=x.device)
+    _call("gdm_simnn_conv1_fwd", _p(x), _p(w), _p(bias), b, h, wd, _p(p1), _p(code1), dt, _stream())
     return p1, code1
 
 
@@ -195,8 +237,8 @@ def simnn_conv2_fwd(p1, w, bias):
     h2, w2 = h1 // 2, w1 // 2
     p2 = torch.empty((b, 32, h2, w2), dtype=p1.dtype, device=p1.device)
     code2 = torch.empty((b, 32, h2, w2), dtype=torch.uint8, device=p1.device)
-    check(_lib.load().gdm_simnn_conv2_fwd(_p(p1), _p(w), _p(bias), b, h1, w1, _p(p2), _p(code2), gdm_dtype(p1),
-                                          _stream()), "gdm_simnn_conv2_fwd")
+    _call("gdm_simnn_conv2_fwd", _p(p1), _p(w), _p(bias), b, h1, w1, _p(p2), _p(code2), gdm_dtype(p1),
+                                          _stream())
     return p2, code2
 
 
@@ -205,36 +247,46 @@ def simnn_conv2_bwd_data(dp2, code2, w, h1, w1):
     assert dp2.is_contiguous() and code2.is_contiguous() and w.is_contiguous()
     b = dp2.shape[0]
     dp1 = torch.empty((b, h1, w1, 16), dtype=dp2.dtype, device=dp2.device)
-    check(_lib.load().gdm_simnn_conv2_bwd_data(_p(dp2), _p(code2), _p(w), b, h1, w1, _p(dp1), gdm_dtype(dp2),
-                                               _stream()), "gdm_simnn_conv2_bwd_data")
+    _call("gdm_simnn_conv2_bwd_data", _p(dp2), _p(code2), _p(w), b, h1, w1, _p(dp1), gdm_dtype(dp2),
+                                               _stream())
     return dp1
 
 
-def simnn_conv2_bwd_weight(dp2, code2, p1):
+def simnn_conv2_bwd_weight(dp2, code2, p1, out=None):
     _need_gpu(dp2, code2, p1)
     assert dp2.is_contiguous() and code2.is_contiguous() and p1.is_contiguous() and dp2.dtype == p1.dtype
     b, h1, w1, _ = p1.shape
-    dw = torch.empty((32, 16, 3, 3), dtype=torch.float32, device=p1.device)
-    db = torch.empty(32, dtype=torch.float32, device=p1.device)
+    if out is not None:
+        dw, db = out
+        assert dw.numel() == 4608 and db.numel() == 32 and dw.is_contiguous() and db.is_contiguous()
+    else:
+        dw = torch.empty((32, 16, 3, 3), dtype=torch.float32, device=p1.device)
+        db = torch.empty(32, dtype=torch.float32, device=p1.device)
     lib = _lib.load()
     nb = lib.gdm_simnn_conv2_bwd_weight_workspace_bytes(b, h1, w1)
     ws = workspace(nb, p1.device)
-    check(lib.gdm_simnn_conv2_bwd_weight(_p(dp2), _p(code2), _p(p1), b, h1, w1, _p(dw), _p(db), gdm_dtype(p1), _p(ws),
-                                         nb, _stream()), "gdm_simnn_conv2_bwd_weight")
+    _call("gdm_simnn_conv2_bwd_weight", _p(dp2), _p(code2), _p(p1), b, h1, w1, _p(dw), _p(db), gdm_dtype(p1), _p(ws),
+                                         nb, _stream())
     return dw, db
 
 
-def simnn_conv1_bwd_weight(dp1, code1, x):
+def simnn_conv1_bwd_weight(dp1, code1, x, out=None, accumulate=False):
     _need_gpu(dp1, code1, x)
     assert dp1.is_contiguous() and code1.is_contiguous() and x.is_contiguous()
     b, h, wd = x.shape
-    dw = torch.empty((16, 1, 2, 2), dtype=torch.float32, device=x.device)
-    db = torch.empty(16, dtype=torch.float32, device=x.device)
+    assert dp1.shape[0] == b and code1.shape[0] == b
+    if out is not None:
+        dw, db = out
+        assert dw.numel() == 64 and db.numel() == 16 and dw.is_contiguous() and db.is_contiguous()
+    else:
+        assert not accumulate
+        dw = torch.empty((16, 1, 2, 2), dtype=torch.float32, device=x.device)
+        db = torch.empty(16, dtype=torch.float32, device=x.device)
     lib = _lib.load()
     nb = lib.gdm_simnn_conv1_bwd_weight_workspace_bytes(b, h, wd)
     ws = workspace(nb, x.device)
-    check(lib.gdm_simnn_conv1_bwd_weight(_p(dp1), _p(code1), _p(x), b, h, wd, _p(dw), _p(db), gdm_dtype(dp1), _p(ws),
-                                         nb, _stream()), "gdm_simnn_conv1_bwd_weight")
+    _call("gdm_simnn_conv1_bwd_weight", _p(dp1), _p(code1), _p(x), b, h, wd, _p(dw), _p(db), gdm_dtype(dp1),
+                                         1 if accumulate else 0, _p(ws), nb, _stream())
     return dw, db
 
 
@@ -245,8 +297,8 @@ def im2col(src, *, planar, b, h, w, c, kh, kw, stride, pad, out_dtype):
     oh = (h + 2 * pad - kh) // stride + 1
     ow = (w + 2 * pad - kw) // stride + 1
     cols = torch.empty((b * oh * ow, c * kh * kw), dtype=_TORCH_DT[out_dtype], device=src.device)
-    check(_lib.load().gdm_im2col(_p(src), gdm_dtype(src), 1 if planar else 0, b, h, w, c, kh, kw, stride, pad, oh, ow,
-                                 _p(cols), out_dtype, _stream()), "gdm_im2col")
+    _call("gdm_im2col", _p(src), gdm_dtype(src), 1 if planar else 0, b, h, w, c, kh, kw, stride, pad, oh, ow,
+                                 _p(cols), out_dtype, _stream())
     return cols, oh, ow
 
 
@@ -255,8 +307,8 @@ def col2im(cols, *, b, h, w, c, kh, kw, stride, pad, oh, ow, out_dtype, planar=F
     assert cols.is_contiguous() and cols.shape == (b * oh * ow, c * kh * kw)
     shape = (b, c, h, w) if planar else (b, h, w, c)
     dst = torch.empty(shape, dtype=_TORCH_DT[out_dtype], device=cols.device)
-    check(_lib.load().gdm_col2im(_p(cols), gdm_dtype(cols), b, h, w, c, kh, kw, stride, pad, oh, ow, _p(dst),
-                                 out_dtype, 1 if planar else 0, _stream()), "gdm_col2im")
+    _call("gdm_col2im", _p(cols), gdm_dtype(cols), b, h, w, c, kh, kw, stride, pad, oh, ow, _p(dst),
+                                 out_dtype, 1 if planar else 0, _stream())
     return dst
 
 
@@ -265,5 +317,5 @@ def permute_pc(src, b, p, c):
     _need_gpu(src)
     assert src.is_contiguous() and src.numel() == b * p * c
     dst = torch.empty((b, c, p), dtype=src.dtype, device=src.device)
-    check(_lib.load().gdm_permute_pc(_p(src), gdm_dtype(src), b, p, c, _p(dst), _stream()), "gdm_permute_pc")
+    _call("gdm_permute_pc", _p(src), gdm_dtype(src), b, p, c, _p(dst), _stream())
     return dst

@@ -1,0 +1,249 @@
+"""Fused training iterations for both GANs (the hot loops GAN_DES/SIMNN.py:276-334 and
+MMGAN_MIDI_DES/network_tests.py:281-321), restructured for MI355X:
+
+  * discriminator parameters, their gradients and Adam moments live in three flat fp32 buffers (the modules'
+    ``.data`` / ``.grad`` become views), so the optimizer is ONE kernel launch and the data-parallel exchange is ONE
+    RCCL all-reduce over a flat bucket (gradients + the discriminator loss scalar);
+  * D(real) and D(fake) of the discriminator step share weights, so they run as one 2B batch: one forward, one
+    backward, gradients arrive already summed (per-sample results are identical, D has no batch statistics);
+  * no autograd graph, no host synchronisation: losses stay on the device until the caller reads them;
+  * what the reference computes but never uses (``gen_loss.backward()`` only fills D's .grad, which the next
+    ``disc_opt.zero_grad()`` wipes; ``gen_opt.step()`` sees no gradients) is executed in faithful mode and skipped
+    with ``elide_dead_backward=True`` -- both modes leave identical parameters and losses.
+
+Generators are never updated by the reference loops (no gradient crosses the DES bridge); only their BatchNorm
+running statistics move, once (model 1) or twice (model 2) per iteration.
+"""
+import torch
+import torch.distributed as dist
+
+from . import functional as Fn
+from . import ops
+from .ops import BF16, F32
+
+
+class FlatBuffers:
+    """Re-home a list of fp32 parameters into one flat buffer (+ flat grad, exp_avg, exp_avg_sq, `extra` tail floats)."""
+
+    def __init__(self, params, extra=0):
+        params = [p for p in params]
+        assert params, "no parameters"
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise ops.GdmError("training runs on a HIP device only: move the modules with .to('cuda') first")
+        self.params = params
+        self.numel = sum(p.numel() for p in params)
+        self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        self.bucket = torch.zeros(self.numel + extra, dtype=torch.float32, device=dev)   # grads | extra scalars
+        self.grad = self.bucket[: self.numel]
+        self.extra = self.bucket[self.numel:]
+        self.exp_avg = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.views, self.grad_views = [], []
+        off = 0
+        for p in params:
+            assert p.dtype == torch.float32 and p.device == dev
+            n = p.numel()
+            v = self.flat[off:off + n].view(p.shape)
+            v.copy_(p.data)
+            p.data = v
+            g = self.grad[off:off + n].view(p.shape)
+            p.grad = g
+            self.views.append(v)
+            self.grad_views.append(g)
+            off += n
+        self.step_count = 0
+
+    def adam(self, lr, betas, eps, grad_scale=1.0):
+        self.step_count += 1
+        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, lr, betas[0], betas[1], eps,
+                      grad_scale)
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
+class _TrainerBase:
+    def _init_common(self, d_params, lr, betas, eps, compute_dtype, elide_dead_backward, process_group):
+        self.dt = Fn.get_compute_dtype() if compute_dtype is None else Fn._NAMES[compute_dtype]
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.elide = elide_dead_backward
+        self.pg = process_group
+        self.world = _world() if process_group is None else dist.get_world_size(process_group)
+        self.d = FlatBuffers(d_params, extra=4)        # extra[0] = disc_loss (rides the all-reduce), [1] = gen_loss
+        self.loss_d = self.d.extra[0:1]
+        self.loss_g = self.d.extra[1:2]
+        self.iterations = 0
+
+    def _reduce_and_step(self):
+        if self.world > 1:
+            # one flat bucket: every D gradient + the local disc_loss mean; SUM here, 1/world folded into Adam
+            dist.all_reduce(self.d.bucket[: self.d.numel + 1], op=dist.ReduceOp.SUM, group=self.pg)
+        self.d.adam(self.lr, self.betas, self.eps, grad_scale=1.0 / self.world)
+
+    def disc_loss_value(self):
+        return self.loss_d.item() / self.world
+
+    def gen_loss_value(self):
+        return self.loss_g.item()
+
+
+class SimnnTrainer(_TrainerBase):
+    """One object per (Generator, Discriminator) pair of model 1; ``step`` = one iteration of SIMNN.py:276-334."""
+
+    def __init__(self, gen, disc, lr=0.00002, betas=(0.5, 0.999), eps=1e-8, compute_dtype=None,
+                 elide_dead_backward=False, process_group=None):
+        self.gen, self.disc = gen, disc
+        self._init_common([disc.conv1.weight, disc.conv1.bias, disc.conv2.weight, disc.conv2.bias, disc.fc1.weight,
+                           disc.fc1.bias, disc.fc2.weight, disc.fc2.bias], lr, betas, eps, compute_dtype,
+                          elide_dead_backward, process_group)
+        self.last_generated = None
+
+    def _gen_state(self):
+        g = self.gen
+        ws = [g.conv1.weight.detach(), g.conv2.weight.detach(), g.conv3.weight.detach(), g.conv4.weight.detach()]
+        bns = [(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.num_batches_tracked)
+               for bn in (g.batch_norm1, g.batch_norm2, g.batch_norm3)]
+        return ws, bns
+
+    @torch.no_grad()
+    def step(self, real, noise, fake):
+        """real (B,H,W) fp32 on the device; noise (B,noise_dim,1,1); fake: (B,H,W) tensor, or a callable
+        ``fake(generated (B,1,20,20) device tensor) -> (B,H,W) tensor`` standing in for matrix_to_wav (SIMNN.py:301).
+        Returns (disc_loss, gen_loss) as 1-element device tensors (this rank's batch means)."""
+        dt = self.dt
+        w1, b1, w2, b2, wf1, bf1, wf2, bf2 = self.d.views
+        g_w1, g_b1, g_w2, g_b2, g_wf1, g_bf1, g_wf2, g_bf2 = self.d.grad_views
+        real = Fn._f32c(real)
+        b, h, w = real.shape
+        # --- generator forward (SIMNN.py:293-296); its output only feeds the (external) bridge
+        ws, bns = self._gen_state()
+        generated, _ = Fn.simnn_gen_forward(noise, ws, bns, self.gen.training, dt)
+        self.last_generated = generated
+        if callable(fake):
+            fake = fake(generated)
+        fake = Fn._f32c(fake.to(real.device))
+        assert fake.shape == real.shape, (fake.shape, real.shape)
+        # --- discriminator step on the 2B batch [real ; fake] (SIMNN.py:282-316)
+        h1, w1s = (h + 1) // 2, (w + 1) // 2
+        adt = ops.torch_dtype(dt)
+        p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=real.device)
+        code1 = torch.empty((2 * b, h1, w1s), dtype=torch.int64, device=real.device)
+        ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
+        ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
+        p2, code2 = ops.simnn_conv2_fwd(p1, w2, b2)
+        flat = p2.view(2 * b, -1)
+        hid = ops.gemm(flat, wf1.t(), bias_n=bf1, act=ops.ACT_RELU, compute=dt)
+        prob = ops.gemm(hid, wf2.t(), bias_n=bf2, act=ops.ACT_SIGMOID, compute=dt).view(-1)
+        dz = torch.empty(2 * b, dtype=torch.float32, device=real.device)
+        ops.bce_with_logits(prob[:b], 0.9, loss_out=self.loss_d, dx_out=dz[:b], fuse_sigmoid_backward=True)
+        ops.bce_with_logits(prob[b:], 0.1, loss_out=self.loss_d, dx_out=dz[b:], fuse_sigmoid_backward=True,
+                            accumulate_loss=True)
+        dz2 = dz.view(2 * b, 1)
+        ops.gemm(dz2.t(), hid, compute=dt, out=g_wf2)
+        ops.colsum(dz2, out=g_bf2)
+        dh = ops.act_bwd(ops.gemm(dz2, wf2, compute=dt), hid, act=ops.ACT_RELU)
+        ops.gemm(dh.t(), flat, compute=dt, out=g_wf1)
+        ops.colsum(dh, out=g_bf1)
+        dp2 = ops.gemm(dh, wf1, compute=dt, out_dtype=dt).view(2 * b, 32, h1 // 2, w1s // 2)
+        ops.simnn_conv2_bwd_weight(dp2, code2, p1, out=(g_w2, g_b2))
+        dp1 = ops.simnn_conv2_bwd_data(dp2, code2, w2, h1, w1s)
+        ops.simnn_conv1_bwd_weight(dp1[:b], code1[:b], real, out=(g_w1, g_b1))
+        ops.simnn_conv1_bwd_weight(dp1[b:], code1[b:], fake, out=(g_w1, g_b1), accumulate=True)
+        self._reduce_and_step()
+        # --- "generator" step (SIMNN.py:322-331): D forward on fake with the updated weights, label 1.0
+        prob_g, saved = Fn.simnn_disc_forward(fake, w1, b1, w2, b2, wf1, bf1, wf2, bf2, dt)
+        if self.elide:
+            ops.bce_with_logits(prob_g, 1.0, loss_out=self.loss_g, want_grad=False)
+        else:
+            _, dzg = ops.bce_with_logits(prob_g, 1.0, loss_out=self.loss_g, fuse_sigmoid_backward=True)
+            Fn.simnn_disc_backward(saved, dzg, w2, wf1, wf2, dt)   # dead values: only D's .grad, wiped next iteration
+        # gen_opt.step(): every generator .grad is None -> no-op
+        self.iterations += 1
+        return self.loss_d, self.loss_g
+
+
+class MmganTrainer(_TrainerBase):
+    """``step`` = one iteration of network_tests.py:281-321 for a MultiModalGAN."""
+
+    def __init__(self, mmgan, lr=0.01, betas=(0.9, 0.999), eps=1e-8, compute_dtype=None, elide_dead_backward=False,
+                 process_group=None):
+        self.mm = mmgan
+        d = mmgan.discriminator
+        self._init_common([d.conv1.weight, d.conv1.bias, d.conv2.weight, d.conv2.bias, d.fc.weight, d.fc.bias], lr,
+                          betas, eps, compute_dtype, elide_dead_backward, process_group)
+        self.last_g1 = self.last_g2 = None
+
+    @staticmethod
+    def _layers(gen):
+        return [(blk[0].weight.detach(), blk[0].bias.detach(), blk[1].weight.detach(), blk[1].bias.detach(),
+                 blk[1].running_mean, blk[1].running_var, blk[1].num_batches_tracked) for blk in gen.gen]
+
+    def _generators_forward(self, noise1, noise2, beats, g1_input):
+        mm, dt = self.mm, self.dt
+        if g1_input is None:   # network_tests.py:83-84: drawn on the CPU generator, then moved
+            g1_input = torch.randn(len(noise1), mm.generator1.input_tensor_dim).to(noise1.device)
+        x1 = torch.cat((noise1, g1_input), dim=1)
+        x2 = torch.cat((noise2, beats), dim=1)
+        o1, _ = Fn.mlp_bn_sigmoid_forward(x1, self._layers(mm.generator1), mm.generator1.training, dt)
+        o2, _ = Fn.mlp_bn_sigmoid_forward(x2, self._layers(mm.generator2), mm.generator2.training, dt)
+        a = mm.generator1.adj_size
+        return o1.view(len(noise1), -1, a[0], a[1]), o2
+
+    @torch.no_grad()
+    def step(self, piano_roll, durations, beats, noise1, noise2, fake_a, fake_b, g1_in_a=None, g1_in_b=None):
+        """fake_a / fake_b: (B,2,128,T) tensors or callables ``f(g1_out, g2_out) -> tensor`` standing in for the
+        DES bridge of the D-step and G-step forwards (network_tests.py:294, 312)."""
+        dt = self.dt
+        w1, b1, w2, b2, wf, bf = self.d.views
+        b = piano_roll.shape[0]
+        dev = piano_roll.device
+        # --- D step (network_tests.py:293-308)
+        g1, g2 = self._generators_forward(noise1, noise2, beats, g1_in_a)
+        self.last_g1, self.last_g2 = g1, g2
+        if callable(fake_a):
+            fake_a = fake_a(g1, g2)
+        x = torch.empty((2 * b, 2) + tuple(piano_roll.shape[1:]), dtype=torch.float32, device=dev)
+        x[:b].copy_(fake_a)                        # [fake ; real]: same order as the two loss terms (304-305)
+        x[b:, 0].copy_(piano_roll)                 # real_data = stack([roll, dur]).permute(1,0,2,3) (290)
+        x[b:, 1].copy_(durations)
+        logits, saved = Fn.dcnn_forward(x, w1, b1, w2, b2, wf, bf, dt)
+        lg = logits.view(-1)
+        dl = torch.empty(2 * b, dtype=torch.float32, device=dev)
+        ops.bce_with_logits(lg[:b], 0.0, loss_out=self.loss_d, dx_out=dl[:b])
+        ops.bce_with_logits(lg[b:], 1.0, loss_out=self.loss_d, dx_out=dl[b:], accumulate_loss=True)
+        grads = Fn.dcnn_backward(saved, dl, w2, wf, dt)
+        for gv, g in zip(self.d.grad_views, grads):
+            gv.copy_(g.view(gv.shape))
+        self._reduce_and_step()
+        # --- "G" step (311-315): both generators run again (2nd BN statistics update), D forward on the new fake
+        g1b, g2b = self._generators_forward(noise1, noise2, beats, g1_in_b)
+        if callable(fake_b):
+            fake_b = fake_b(g1b, g2b)
+        logits_g, saved_g = Fn.dcnn_forward(fake_b, w1, b1, w2, b2, wf, bf, dt)
+        if self.elide:
+            ops.bce_with_logits(logits_g.view(-1), 1.0, loss_out=self.loss_g, want_grad=False)
+        else:
+            _, dlg = ops.bce_with_logits(logits_g.view(-1), 1.0, loss_out=self.loss_g)
+            Fn.dcnn_backward(saved_g, dlg, w2, wf, dt)     # dead values (only D's .grad in the reference)
+        self.iterations += 1
+        return self.loss_d, self.loss_g
+
+
+class StepLR:
+    """torch.optim.lr_scheduler.StepLR(step_size, gamma) for a trainer (network_tests.py:257-258, 328-329)."""
+
+    def __init__(self, trainer, step_size, gamma=0.1):
+        self.trainer, self.step_size, self.gamma = trainer, step_size, gamma
+        self.base_lr = trainer.lr
+        self.last_epoch = 0
+
+    def step(self):
+        self.last_epoch += 1
+        self.trainer.lr = self.base_lr * self.gamma ** (self.last_epoch // self.step_size)
+
+    def get_last_lr(self):
+        return [self.trainer.lr]

@@ -49,16 +49,18 @@ int gdm_gemm(const void* A, int a_dtype, int64_t sam, int64_t sak,
  * x: n fp32 values fed to BCEWithLogitsLoss (for model 1 these are already sigmoid outputs: SIMNN.py:141 + 289),
  * target: one label value for the whole batch (0.9/0.1/1.0 at SIMNN.py:284,308,326; 1/0 at network_tests.py:286-287).
  * Writes loss[0] (mean) and, if dx != NULL, dx[i] = grad_scale * (sigmoid(x[i]) - target) / n.
- * If pre_sigmoid_z != NULL the chain through model 1's final sigmoid is fused: x[i] must equal sigmoid(z[i]) and
- * dx[i] is d loss / d z[i].  n <= 65536 (one workgroup, fixed-order reduction => deterministic).                   */
+ * If fuse_sigmoid_backward the chain through model 1's final sigmoid is fused: x[i] is sigmoid(z[i]) and dx[i] is
+ * d loss / d z[i].  accumulate_loss adds the mean to loss[0] instead of overwriting it (disc_loss = fake + real,
+ * SIMNN.py:314).  n <= 65536 (one workgroup, fixed-order reduction => deterministic).                              */
 int gdm_bce_with_logits(const float* x, float target, int n, float grad_scale, float* loss, float* dx,
-                        int fuse_sigmoid_backward, void* stream);
+                        int fuse_sigmoid_backward, int accumulate_loss, void* stream);
 
 /* ---- optimizer (torch.optim.Adam single-tensor step, SIMNN.py:258-259,316; network_tests.py:253-254,308) -------
  * One flat fp32 range: p, g, m (exp_avg), v (exp_avg_sq) of n elements; `step` is the 1-based step count.
- * bias corrections are computed on the host in double like torch does.                                            */
+ * bias corrections are computed on the host in double like torch does.  grad_scale multiplies g on the fly
+ * (1/world_size after a summed gradient all-reduce; 1 otherwise).                                                  */
 int gdm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
-                  float beta2, float eps, void* stream);
+                  float beta2, float eps, float grad_scale, void* stream);
 
 /* ---- batch norm, training mode, rows x channels matrices (aten::native_batch_norm + activation) ----------------
  * y: (rows, channels) fp32 pre-norm values (row-major).  Computes per-channel batch mean / biased variance with a
@@ -111,7 +113,8 @@ int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2, const void
 /* dW1 (16,1,2,2), db1 (16) from dp1 routed through code1 (pool argmax + ReLU mask) and the input x. */
 size_t gdm_simnn_conv1_bwd_weight_workspace_bytes(int B, int H, int W);
 int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1, const float* x, int B, int H, int W,
-                               float* dw, float* db, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+                               float* dw, float* db, int dtype, int accumulate, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* ---- generic convolution lowering helpers (model 2 discriminator, model 1 generator) ----------------------------
  * im2col for Conv2d fwd / dW and col2im (gather form, deterministic) for Conv2d dX and ConvTranspose2d fwd.

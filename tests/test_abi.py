@@ -39,7 +39,7 @@ def test_probes_and_error_reporting(lib_path):
     # argument validation happens on the host before any launch: safe without a GPU
     rc = lib.gdm_gemm(None, 0, 0, 0, None, 0, 0, 0, None, 0, 0, 0, 4, 4, 4, None, None, 0, 0.0, 0, 1, None, 0, None)
     assert rc == -1 and b"null operand" in lib.gdm_last_error()
-    rc = lib.gdm_bce_with_logits(None, 0.0, 4, 1.0, None, None, 0, None)
+    rc = lib.gdm_bce_with_logits(None, 0.0, 4, 1.0, None, None, 0, 0, None)
     assert rc == -1
 
 

@@ -1,0 +1,225 @@
+"""GPU: model 2 (MMGAN_MIDI_DES/network_tests.py surface) against the golden vectors captured from the reference
+and against the CPU oracle.  Tolerances as in tests/test_simnn_gpu.py; the D losses of this model grow to O(100)
+within a few iterations (Adam lr 0.01 on un-normalised piano-roll velocities), so free-running losses are compared
+relatively (2e-3) like the oracle-vs-golden test does.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gan_des_midi_music_gen_amd import functional as Fn, network_tests as NT, optim, synthetic  # noqa: E402
+from gan_des_midi_music_gen_amd.train import MmganTrainer, StepLR  # noqa: E402
+from oracle import mmgan as om, steps as ost  # noqa: E402  (checker only)
+
+from helpers import assert_summary_close, load_golden, rel_l2, tensor_summary, weight_digest  # noqa: E402
+
+DEV = "cuda"
+
+
+def _mm(seed, t=50, provider=None):
+    torch.manual_seed(seed)
+    return NT.MultiModalGAN(z_dim=50, adj_size=(64, 64), roll_size=(2, 128, t), input_dim=50, output_dim=20,
+                            instrument=0, start=100, end=150, device="cpu", fake_provider=provider)
+
+
+def _close(got, want, rtol, what=""):
+    got = torch.as_tensor(got).detach().float().cpu()
+    want = torch.as_tensor(want).detach().float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = want.abs().max().item() + 1e-30
+    err = (got - want).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def test_same_seed_gives_reference_weights_and_keys():
+    g = load_golden("mmgan_modules.npz")
+    mm = _mm(int(g["seed"]))
+    mlpd = NT.Discriminator(roll_size=(2, 128, 50))
+    for k, v in mm.state_dict().items():
+        assert weight_digest(v) == g[f"digest/mmgan/{k}"], k
+    for k, v in mlpd.state_dict().items():
+        assert weight_digest(v) == g[f"digest/mlpd/{k}"], k
+
+
+def test_modules_match_golden_fp32():
+    g = load_golden("mmgan_modules.npz")
+    mm = _mm(int(g["seed"]))
+    mlpd = NT.Discriminator(roll_size=(2, 128, 50))
+    mm.to(DEV), mlpd.to(DEV)
+    d = {k[3:]: torch.from_numpy(g[k]).to(DEV) for k in g.files if k.startswith("in/")}
+    mm.train()
+    g1 = mm.generator1(d["noise1"], d["g1_in_a"])
+    g2 = mm.generator2(d["noise2"], d["beats"])
+    assert g1.shape == (4, 1, 64, 64) and g2.shape == (4, 20)
+    _close(g1, g["g1_out_train"], 2e-5, "G1 train")
+    _close(g2, g["g2_out_train"], 2e-5, "G2 train")
+    for k, v in mm.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            _close(v, g[f"after_fwd/{k}"], 5e-5, k)
+    ((g1 * torch.from_numpy(g["g1_bwd_R"]).to(DEV)).sum() + (g2 * torch.from_numpy(g["g2_bwd_R"]).to(DEV)).sum()
+     ).backward()
+    for name, gmod in (("g1", mm.generator1), ("g2", mm.generator2)):
+        for k, p in gmod.named_parameters():
+            if k.endswith(".0.bias"):   # exactly-zero true gradient in front of train-mode BN: rounding noise only
+                assert p.grad.norm().item() < 1e-3, k
+                continue
+            assert_summary_close(tensor_summary(p.grad), g[f"{name}_grad/{k}"], 5e-4, 1e-9, f"{name}.{k}")
+    mm.eval()
+    with torch.no_grad():
+        _close(mm.generator1(d["noise1"], d["g1_in_a"]), g["g1_out_eval"], 2e-5, "G1 eval")
+        _close(mm.generator2(d["noise2"], d["beats"]), g["g2_out_eval"], 2e-5, "G2 eval")
+    mm.train()
+    b = 4
+    real_data = torch.stack([d["piano_roll"], d["durations"]]).permute(1, 0, 2, 3)   # non-contiguous, as upstream
+    lo_f, lo_r = mm.discriminator(d["fake_a"]), mm.discriminator(real_data)
+    _close(lo_f, g["dcnn_logits_fake"], 1e-4, "DCNN logits fake")
+    _close(lo_r, g["dcnn_logits_real"], 1e-4, "DCNN logits real")
+    lf = F.binary_cross_entropy_with_logits(lo_f.squeeze(), torch.zeros(b, device=DEV))
+    lr = F.binary_cross_entropy_with_logits(lo_r.squeeze(), torch.ones(b, device=DEV))
+    assert abs(lf.item() - float(g["loss_fake"])) < 1e-4 * max(1, abs(float(g["loss_fake"])))
+    assert abs(lr.item() - float(g["loss_real"])) < 1e-4 * max(1, abs(float(g["loss_real"])))
+    (lf + lr).backward()
+    for k, p in mm.discriminator.named_parameters():
+        assert rel_l2(p.grad, g[f"dcnn_grad/{k}"]) < 2e-4, (k, rel_l2(p.grad, g[f"dcnn_grad/{k}"]))
+    mo = mlpd(real_data.reshape(b, -1))
+    _close(mo, g["mlpd_out"], 1e-4, "MLP discriminator")
+    mo.sum().backward()
+    for k, p in mlpd.named_parameters():
+        assert_summary_close(tensor_summary(p.grad), g[f"mlpd_grad/{k}"], 5e-4, 1e-7, k)
+
+
+def test_multimodal_gan_forward_contract():
+    calls = []
+
+    def provider(g1, g2, count):
+        calls.append((tuple(g1.shape), tuple(g2.shape), count, g1.requires_grad))
+        return [np.zeros((2, 128, 50), dtype=np.float32) for _ in range(len(g1))], 3
+
+    mm = _mm(0, provider=provider).to(DEV)
+    n1, n2 = torch.randn(4, 50, device=DEV), torch.randn(4, 50, device=DEV)
+    beats = synthetic.mmgan_inputs(4, 50, seed=1, device=DEV)["beats"]
+    logits, failed = mm(n1, n2, beats, 7)
+    assert logits.shape == (4, 1) and failed == 3
+    assert calls == [((4, 1, 64, 64), (4, 20), 7, False)]
+    with pytest.raises(RuntimeError):
+        _mm(0).to(DEV)(n1, n2, beats, 1)
+
+
+def test_trainer_reproduces_golden_iterations_fp32():
+    g = load_golden("mmgan_steps.npz")
+    b = int(g["batch"])
+    results = {}
+    for elide in (False, True):
+        mm = _mm(int(g["seed"])).to(DEV)
+        mm.train()
+        tr = MmganTrainer(mm, lr=0.01, compute_dtype="fp32", elide_dead_backward=elide)
+        dls, gls = [], []
+        for it in range(10):
+            d = synthetic.mmgan_inputs(b, 50, seed=200 + it, device=DEV)
+            dl, gl = tr.step(d["piano_roll"], d["durations"], d["beats"], d["noise1"], d["noise2"], d["fake_a"],
+                             d["fake_b"], g1_in_a=d["g1_in_a"], g1_in_b=d["g1_in_b"])
+            dls.append(dl.item())
+            gls.append(gl.item())
+            if it == 0:
+                _close(tr.last_g1, g["g1_out_it1"], 2e-5, "generated DES matrices")
+                _close(tr.last_g2, g["g2_out_it1"], 2e-5, "generated DES/MIDI parameters")
+            if it + 1 in (1, 2):
+                for k, v in mm.discriminator.state_dict().items():
+                    np.testing.assert_allclose(v.cpu().numpy(), g[f"dcnn_after_{it + 1}/{k}"], rtol=0, atol=2e-3,
+                                               err_msg=k)
+            if it + 1 in (1, 2, 10):
+                for k, v in mm.state_dict().items():
+                    if "running" in k or "num_batches" in k:
+                        np.testing.assert_allclose(v.cpu().numpy(), g[f"bn_after_{it + 1}/{k}"], rtol=1e-4, atol=1e-5,
+                                                   err_msg=k)
+        for it in range(10):
+            assert abs(dls[it] - g["disc_losses"][it]) <= 2e-3 * max(1.0, abs(g["disc_losses"][it])), (it, dls[it])
+            assert abs(gls[it] - g["gen_losses"][it]) <= 2e-3 * max(1.0, abs(g["gen_losses"][it])), (it, gls[it])
+        assert abs(dls[0] - g["disc_losses"][0]) < 1e-4 * max(1, g["disc_losses"][0])
+        results[elide] = (dls, gls, mm.discriminator.fc.weight.detach().clone())
+        assert all(p.grad is None for p in mm.generator1.parameters())
+        sched = StepLR(tr, step_size=30, gamma=0.1)
+        lrs = [tr.lr]
+        for _ in range(60):
+            sched.step()
+            lrs.append(tr.lr)
+        np.testing.assert_allclose([lrs[0], lrs[29], lrs[30], lrs[59], lrs[60]], g["steplr_lrs"], rtol=1e-12)
+    assert results[False][0] == results[True][0] and results[False][1] == results[True][1]
+    assert torch.equal(results[False][2], results[True][2])
+
+
+@pytest.mark.parametrize("mode,tol_out,tol_grad", [("fp32", 1e-4, 5e-4), ("bf16", 2e-2, 5e-2)])
+@pytest.mark.parametrize("t", [50, 256])
+def test_dcnn_vs_oracle(mode, tol_out, tol_grad, t):
+    torch.manual_seed(4)
+    ref = om.DiscriminatorCNN(roll_size=(2, 128, t))
+    d = NT.DiscriminatorCNN(roll_size=(2, 128, t))
+    d.load_state_dict(ref.state_dict(), strict=True)
+    d.to(DEV)
+    d.compute_dtype = mode
+    x = synthetic.mmgan_inputs(5, t, seed=21)["fake_a"]
+    lo_ref = ref(x)
+    l_ref = ost.bce_with_logits(lo_ref.squeeze(), torch.ones(5))
+    l_ref.backward()
+    lo = d(x.to(DEV))
+    _close(lo, lo_ref, tol_out, f"DCNN logits {mode} T={t}")
+    F.binary_cross_entropy_with_logits(lo.squeeze(), torch.ones(5, device=DEV)).backward()
+    for (k, pr), (_, pg) in zip(ref.named_parameters(), d.named_parameters()):
+        assert rel_l2(pg.grad, pr.grad) < tol_grad, (k, rel_l2(pg.grad, pr.grad))
+
+
+def test_bf16_trainer_tracks_fp32_losses():
+    b = 16
+    losses = {}
+    for mode in ("fp32", "bf16"):
+        mm = _mm(9).to(DEV)
+        tr = MmganTrainer(mm, lr=0.01, compute_dtype=mode)
+        out = []
+        for it in range(3):
+            d = synthetic.mmgan_inputs(b, 50, seed=400 + it, device=DEV)
+            dl, gl = tr.step(d["piano_roll"], d["durations"], d["beats"], d["noise1"], d["noise2"], d["fake_a"],
+                             d["fake_b"], g1_in_a=d["g1_in_a"], g1_in_b=d["g1_in_b"])
+            out.append((dl.item(), gl.item()))
+        losses[mode] = np.array(out)
+    np.testing.assert_allclose(losses["bf16"][0], losses["fp32"][0], rtol=2e-2, atol=2e-2)
+    assert np.all(np.isfinite(losses["bf16"]))
+
+
+def test_full_size_properties():
+    """BASELINE config 3/4 size (256 rolls per GPU): batch independence, gradient additivity, determinism."""
+    b = 256
+    torch.manual_seed(2)
+    d = NT.DiscriminatorCNN(roll_size=(2, 128, 50)).to(DEV)
+    x = synthetic.mmgan_inputs(b, 50, seed=6, device=DEV)["fake_a"]
+    with torch.no_grad():
+        full, again = d(x), d(x)
+        parts = torch.cat([d(x[:96]), d(x[96:])])
+    assert torch.equal(full, again)
+    assert rel_l2(parts, full) < 1e-5
+
+    def grads(sl):
+        d.zero_grad()
+        lo = d(x[sl])
+        lo.backward(torch.ones_like(lo) / b)
+        return [q.grad.detach().clone() for q in d.parameters()]
+
+    g_all, g_a, g_b = grads(slice(0, b)), grads(slice(0, 128)), grads(slice(128, b))
+    for ga, g1, g2 in zip(g_all, g_a, g_b):
+        assert rel_l2(ga, g1 + g2) < 1e-4
+    assert all(torch.equal(u, v) for u, v in zip(g_all, grads(slice(0, b))))
+
+
+def test_training_loop_entry_point(tmp_path):
+    d_losses, g_losses = NT.training_loop(8, num_epochs=2, steps_per_epoch=3, save_dir=str(tmp_path), seed=0,
+                                          log=lambda *_: None)
+    assert len(d_losses) == 3 and len(g_losses) == 3 and np.all(np.isfinite(d_losses + g_losses))
+    ck = tmp_path / "models" / "mmgan_64_64_epoch_2.pth"
+    assert ck.exists() and (tmp_path / "losses" / "disc_losses_epoch_1.pkl").exists()
+    sd = torch.load(ck, weights_only=True)
+    fresh = _mm(0)
+    fresh.load_state_dict(sd, strict=True)
+    # 2 epochs x 3 iterations x 2 generator forwards per iteration
+    assert int(sd["generator1.gen.0.1.num_batches_tracked"]) == 12
