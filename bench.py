@@ -107,11 +107,24 @@ def build_mmgan(args, rank, dev):
     return tr, step
 
 
+def host_cores():
+    """Threads for the CPU baseline: the affinity mask, clipped by the cgroup CPU quota and by GDM_CPU_THREADS
+    (the GPU boxes expose 256 hardware threads but give one job a 16-CPU share; oversubscribing is 20x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("GDM_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(args):
     """Oracle (CPU restatement of the reference loop) on the host cores; bounded sample, same geometry/mode."""
     from oracle import simnn as osn, mmgan as om, steps as ost
     from gan_des_midi_music_gen_amd import synthetic
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     torch.set_num_threads(cores)
     elide = args.mode == "elided"
     if args.workload == "simnn":

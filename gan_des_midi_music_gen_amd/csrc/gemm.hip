@@ -10,7 +10,7 @@
 // Both operand tiles are stored k-contiguous ([m][k], [n][k]) whatever the global strides are; the global->LDS map is
 // chosen per operand so that consecutive lanes touch consecutive addresses (k-fastest when the k stride is 1,
 // m/n-fastest otherwise).
-#include "gdm_common.h"
+#include "gemm_common.h"
 
 namespace {
 
@@ -19,22 +19,6 @@ constexpr int BM = 64, BN = 64, NT = 256;
 template <typename CT> struct GemmCfg;
 template <> struct GemmCfg<float> { static constexpr int KT = 32, LD = 34; };
 template <> struct GemmCfg<__bf16> { static constexpr int KT = 64, LD = 72; };
-
-struct GemmArgs {
-  const void* A; int64_t sam, sak;
-  const void* B; int64_t sbk, sbn;
-  void* C; int c_dtype; int64_t scm, scn;
-  int M, N, K;
-  const float* bias_n; const float* bias_m; int act; float slope;
-  int split_k, k_per_split; float* ws;
-};
-
-__device__ __forceinline__ void epilogue_store(const GemmArgs& g, int m, int n, float v) {
-  if (g.bias_n) v += g.bias_n[n];
-  if (g.bias_m) v += g.bias_m[m];
-  v = apply_act(v, g.act, g.slope);
-  store_from_f32(g.C, g.c_dtype, (int64_t)m * g.scm + (int64_t)n * g.scn, v);
-}
 
 template <typename CT, typename TA, typename TB>
 __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
@@ -126,7 +110,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
         const int n = n0 + wn * 32 + j * 16 + lr;
         if (m < g.M && n < g.N) {
           if (g.split_k > 1) g.ws[((int64_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
-          else epilogue_store(g, m, n, acc[i][j][r]);
+          else gemm_epilogue_store(g, m, n, acc[i][j][r]);
         }
       }
 }
@@ -137,7 +121,16 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs g) {
   const int m = (int)(idx / g.N), n = (int)(idx % g.N);
   float s = 0.f;
   for (int z = 0; z < g.split_k; ++z) s += g.ws[(int64_t)z * g.M * g.N + idx];
-  epilogue_store(g, m, n, s);
+  gemm_epilogue_store(g, m, n, s);
+}
+
+int launch_splitk_reduce(const GemmArgs& g, hipStream_t s) {
+  if (g.split_k > 1) {
+    const int64_t total = (int64_t)g.M * g.N;
+    hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g);
+    GDM_LAUNCH_OK("gdm_gemm(split-k reduce)");
+  }
+  return GDM_OK;
 }
 
 template <typename CT>
@@ -148,12 +141,7 @@ int launch_gemm(const GemmArgs& g, int a_dtype, int b_dtype, hipStream_t s) {
   else if (b_dtype == GDM_F32) hipLaunchKernelGGL((gemm_kernel<CT, __bf16, float>), grid, block, 0, s, g);
   else hipLaunchKernelGGL((gemm_kernel<CT, __bf16, __bf16>), grid, block, 0, s, g);
   GDM_LAUNCH_OK("gdm_gemm");
-  if (g.split_k > 1) {
-    const int64_t total = (int64_t)g.M * g.N;
-    hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g);
-    GDM_LAUNCH_OK("gdm_gemm(split-k reduce)");
-  }
-  return GDM_OK;
+  return launch_splitk_reduce(g, s);
 }
 
 }  // namespace
@@ -168,7 +156,9 @@ extern "C" int gdm_gemm(const void* A, int a_dtype, int64_t sam, int64_t sak, co
               "gdm_gemm: bad dtype");
   GDM_REQUIRE(act >= GDM_ACT_NONE && act <= GDM_ACT_SIGMOID, "gdm_gemm: bad activation %d", act);
   GDM_REQUIRE(split_k >= 1 && split_k <= 65535, "gdm_gemm: bad split_k %d", split_k);
-  const int KT = compute_dtype == GDM_BF16 ? GemmCfg<__bf16>::KT : GemmCfg<float>::KT;
+  GemmArgs probe{A, sam, sak, B, sbk, sbn, C, c_dtype, scm, scn, M, N, K, bias_n, bias_m, act, slope, 1, K, nullptr};
+  const bool fast = compute_dtype == GDM_BF16 && gdm_gemm_bf16_fast_ok(probe, a_dtype, b_dtype);
+  const int KT = fast ? GDM_GEMM_FAST_KT : (compute_dtype == GDM_BF16 ? GemmCfg<__bf16>::KT : GemmCfg<float>::KT);
   int tiles = (K + KT - 1) / KT;
   if (split_k > tiles) split_k = tiles;
   int per = (tiles + split_k - 1) / split_k;
@@ -183,6 +173,11 @@ extern "C" int gdm_gemm(const void* A, int a_dtype, int64_t sam, int64_t sak, co
   GemmArgs g{A, sam, sak, B, sbk, sbn, C, c_dtype, scm, scn, M, N, K, bias_n, bias_m, act, slope,
              split_k, per * KT, (float*)workspace};
   hipStream_t s = (hipStream_t)stream;
+  if (fast) {
+    int rc = gdm_gemm_bf16_fast_launch(g, a_dtype, b_dtype, s);
+    if (rc != GDM_OK) return rc;
+    return launch_splitk_reduce(g, s);
+  }
   return compute_dtype == GDM_BF16 ? launch_gemm<__bf16>(g, a_dtype, b_dtype, s)
                                    : launch_gemm<float>(g, a_dtype, b_dtype, s);
 }

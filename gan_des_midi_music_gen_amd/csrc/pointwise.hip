@@ -110,19 +110,29 @@ __global__ __launch_bounds__(256) void bn_partial_stats(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize(const float* __restrict__ ws, int chunks, int rows, int C,
-                                                   float momentum, float eps, float* __restrict__ running_mean,
-                                                   float* __restrict__ running_var, int64_t* __restrict__ nbt,
-                                                   float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c == 0 && nbt) nbt[0] += 1;
-  if (c >= C) return;
+// Stage 2: a 1024-thread workgroup owns 64 channels; wave w merges chunks w, w+16, ... in order, then the 16 partial
+// triples are merged in wave order (fixed order => deterministic).
+__global__ __launch_bounds__(1024) void bn_finalize(const float* __restrict__ ws, int chunks, int rows, int C,
+                                                    float momentum, float eps, float* __restrict__ running_mean,
+                                                    float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                    float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  __shared__ Welford part[16][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
   Welford t{0.f, 0.f, 0.f};
-  for (int k = 0; k < chunks; ++k) {
-    const float* o = ws + ((int64_t)k * C + c) * 3;
-    Welford b{o[0], o[1], o[2]};
-    welford_merge(t, b);
-  }
+  if (c < C)
+    for (int k = wv; k < chunks; k += 16) {
+      const float* o = ws + ((int64_t)k * C + c) * 3;
+      Welford b{o[0], o[1], o[2]};
+      welford_merge(t, b);
+    }
+  part[wv][lane] = t;
+  __syncthreads();
+  if (wv != 0 || c >= C) return;
+  t = part[0][lane];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) welford_merge(t, part[w][lane]);
   const float var_b = t.m2 / (float)rows;
   save_mean[c] = t.mean;
   save_invstd[c] = 1.0f / sqrtf(var_b + eps);
@@ -331,7 +341,7 @@ extern "C" int gdm_bn_act_fwd(const float* y, int rows, int channels, const floa
     const int chunk_rows = (rows + chunks - 1) / chunks;
     hipLaunchKernelGGL(bn_partial_stats, dim3((C + 63) / 64, chunks), dim3(256), 0, s, y, rows, C, chunk_rows,
                        (float*)workspace);
-    hipLaunchKernelGGL(bn_finalize, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, chunks, rows, C,
+    hipLaunchKernelGGL(bn_finalize, dim3((C + 63) / 64), dim3(1024), 0, s, (const float*)workspace, chunks, rows, C,
                        momentum, eps, running_mean, running_var, num_batches_tracked, save_mean, save_invstd);
   } else {
     GDM_REQUIRE(running_mean && running_var, "gdm_bn_act_fwd: eval mode needs running statistics");

@@ -143,13 +143,32 @@ __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restri
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-__global__ __launch_bounds__(128) void conv1_bwd_weight_final(const float* __restrict__ slabs, int nslabs,
+// Fixed-order parallel sum of `nslabs` slabs of `width` floats: a 1024-thread workgroup owns 64 consecutive
+// elements; wave w adds slabs w, w+16, ... (coalesced 256-B rows), then the 16 partials are added in wave order.
+__global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict__ slabs, int nslabs, int width,
+                                                        float* __restrict__ out) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (i < width)
+    for (int k = wv; k < nslabs; k += 16) s += slabs[(int64_t)k * width + i];
+  part[wv][lane] = s;
+  __syncthreads();
+  if (wv == 0 && i < width) {
+    float t = part[0][lane];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) t += part[w][lane];
+    out[i] = t;
+  }
+}
+
+__global__ __launch_bounds__(128) void conv1_bwd_weight_final(const float* __restrict__ sums,
                                                               float* __restrict__ dw, float* __restrict__ db,
                                                               int accumulate) {
   const int i = threadIdx.x;
   if (i >= 80) return;
-  float s = 0.f;
-  for (int k = 0; k < nslabs; ++k) s += slabs[(int64_t)k * 80 + i];
+  const float s = sums[i];
   float* dst = i < 64 ? dw + i : db + (i - 64);
   *dst = accumulate ? *dst + s : s;
 }
@@ -575,12 +594,11 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void conv2_bwd_weight_final(const float* __restrict__ slabs, int nslabs,
+__global__ __launch_bounds__(256) void conv2_bwd_weight_final(const float* __restrict__ sums,
                                                               float* __restrict__ dw, float* __restrict__ db) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 4608 + 32) return;
-  float s = 0.f;
-  for (int k = 0; k < nslabs; ++k) s += slabs[(int64_t)k * (4608 + 32) + i];
+  const float s = sums[i];
   if (i < 4608) {
     const int ci = i & 15, tap = (i >> 4) % 9, o = i / 144;
     dw[(o * 16 + ci) * 9 + tap] = s;
@@ -617,7 +635,7 @@ extern "C" int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* 
 
 extern "C" size_t gdm_simnn_conv1_bwd_weight_workspace_bytes(int B, int H, int W) {
   const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
-  return (size_t)conv1_slabs(total) * 80 * sizeof(float);
+  return (size_t)(conv1_slabs(total) + 1) * 80 * sizeof(float);
 }
 
 extern "C" int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1, const float* x, int B, int H, int W,
@@ -634,8 +652,9 @@ extern "C" int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_bwd_weight_kernel<T>, dim3(nslabs), dim3(256), 0, s, (const T*)dp1, code1,
                                        x, B, H, W, H1, W1, (float*)workspace));
-  hipLaunchKernelGGL(conv1_bwd_weight_final, dim3(1), dim3(128), 0, s, (const float*)workspace, nslabs, dw, db,
-                     accumulate);
+  float* sums = (float*)workspace + (size_t)nslabs * 80;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(2), dim3(1024), 0, s, (const float*)workspace, nslabs, 80, sums);
+  hipLaunchKernelGGL(conv1_bwd_weight_final, dim3(1), dim3(128), 0, s, (const float*)sums, dw, db, accumulate);
   GDM_LAUNCH_OK("gdm_simnn_conv1_bwd_weight");
   return GDM_OK;
 }
@@ -683,7 +702,7 @@ extern "C" int gdm_simnn_conv2_bwd_data(const void* dp2, const uint8_t* code2, c
 
 extern "C" size_t gdm_simnn_conv2_bwd_weight_workspace_bytes(int B, int H1, int W1) {
   const int n_units = B * ((H1 + 1) / 2) * ((W1 + COLS - 1) / COLS);
-  return (size_t)conv2w_blocks(n_units) * (4608 + 32) * sizeof(float);
+  return (size_t)(conv2w_blocks(n_units) + 1) * (4608 + 32) * sizeof(float);
 }
 
 extern "C" int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2, const void* p1, int B, int H1, int W1,
@@ -724,8 +743,11 @@ extern "C" int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2,
     hipLaunchKernelGGL(conv2_bwd_weight_kernel<float>, dim3(nblocks), dim3(256), sm, s, (const float*)dp2, code2,
                        (const float*)p1, B, H1, W1, H2, W2, n_ctiles, n_units, (float*)workspace);
   }
-  hipLaunchKernelGGL(conv2_bwd_weight_final, dim3((4608 + 32 + 255) / 256), dim3(256), 0, s, (const float*)workspace,
-                     nblocks, dw, db);
+  float* sums = (float*)workspace + (size_t)nblocks * (4608 + 32);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((4608 + 32 + 63) / 64), dim3(1024), 0, s, (const float*)workspace, nblocks,
+                     4608 + 32, sums);
+  hipLaunchKernelGGL(conv2_bwd_weight_final, dim3((4608 + 32 + 255) / 256), dim3(256), 0, s, (const float*)sums, dw,
+                     db);
   GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_weight");
   return GDM_OK;
 }

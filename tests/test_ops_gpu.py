@@ -73,6 +73,35 @@ def test_gemm_shapes_and_epilogues(comp, m, n, k):
     _close(out, ar @ wr.t() + bm[:, None], rt, "bias_m")
 
 
+@pytest.mark.parametrize("ta", ["f32", "bf16"])
+@pytest.mark.parametrize("tb", ["f32", "bf16"])
+@pytest.mark.parametrize("a_kmaj", [True, False])
+@pytest.mark.parametrize("b_kmaj", [True, False])
+def test_gemm_bf16_vector_path_all_layouts(ta, tb, a_kmaj, b_kmaj):
+    """The 128x128 vectorised kernel: every (dtype, K-major / row-major) operand combination, ragged M/N/K tails,
+    fused epilogue, split-K, bf16 output."""
+    g = torch.Generator().manual_seed(17)
+    m, n, k = 200, 264, 136
+    a = torch.randn(m, k, generator=g)
+    b = torch.randn(k, n, generator=g) / k ** 0.5
+    bias = torch.randn(n, generator=g)
+    tda = torch.float32 if ta == "f32" else torch.bfloat16
+    tdb = torch.float32 if tb == "f32" else torch.bfloat16
+    # physical layouts: K-major A = (m,k) contiguous; row-major A = stored as (k,m), viewed transposed
+    ad = a.to(tda).to(DEV).contiguous() if a_kmaj else a.t().contiguous().to(tda).to(DEV).t()
+    bd = b.t().contiguous().to(tdb).to(DEV).t() if b_kmaj else b.to(tdb).to(DEV).contiguous()
+    ref = _rb(a) @ _rb(b)
+    for split in (1, 3):
+        out = ops.gemm(ad, bd, bias_n=bias.to(DEV), act=ACT_LEAKY, slope=0.2, compute=BF16, split_k=split)
+        _close(out, F.leaky_relu(ref + bias, 0.2), 2e-3, f"fast gemm split={split}")
+    out = ops.gemm(ad, bd, compute=BF16, out_dtype=BF16)
+    _close(out, ref, 1e-2, "fast gemm bf16 out")
+    if b_kmaj:   # N not a multiple of 4 -> scalar epilogue (only reachable with a K-major B)
+        bd2 = b[:, :262].t().contiguous().to(tdb).to(DEV).t()
+        out = ops.gemm(ad, bd2, bias_n=bias[:262].to(DEV), compute=BF16)
+        _close(out, ref[:, :262] + bias[:262], 2e-3, "fast gemm ragged N")
+
+
 def test_bce_with_logits():
     g = torch.Generator().manual_seed(3)
     for n, target in ((16, 0.9), (256, 0.1), (2048, 1.0), (7, 0.0)):
