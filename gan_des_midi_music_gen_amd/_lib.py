@@ -28,7 +28,11 @@ SIGNATURES = {
     "gdm_colsum": (_I, [_P, _I, _I, _I, _P, _P, _Z, _P]),
     "gdm_cast": (_I, [_P, _I, _P, _I, _L, _P]),
     "gdm_simnn_conv1_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "gdm_simnn_conv2_pack_bytes": (_Z, [_I]),
+    "gdm_simnn_conv2_pack": (_I, [_P, _I, _P, _P]),
     "gdm_simnn_conv2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "gdm_simnn_conv2_bwd_fused_workspace_bytes": (_Z, [_I, _I, _I]),
+    "gdm_simnn_conv2_bwd_fused": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _Z, _P]),
     "gdm_simnn_conv2_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P]),
     "gdm_simnn_conv2_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I]),
     "gdm_simnn_conv2_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
@@ -36,7 +40,7 @@ SIGNATURES = {
     "gdm_simnn_conv1_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _P, _Z, _P]),
     "gdm_im2col": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "gdm_col2im": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
-    "gdm_permute_pc": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "gdm_permute_pc": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
 }
 
 _lock = threading.Lock()

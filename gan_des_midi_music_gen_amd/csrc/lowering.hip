@@ -58,13 +58,24 @@ __global__ __launch_bounds__(256) void col2im_kernel(const void* __restrict__ co
   }
 }
 
-// dst[b][c][p] = src[b][p][c]  (src viewed as (B, P, C)); used in both directions by swapping P and C
-__global__ __launch_bounds__(256) void permute_pc_kernel(const void* __restrict__ src, int dt, int B, int P, int C,
-                                                         void* __restrict__ dst) {
-  const int64_t total = (int64_t)B * P * C;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int p = (int)(i % P), c = (int)((i / P) % C), b = (int)(i / ((int64_t)P * C));
-    store_from_f32(dst, dt, i, load_as_f32(src, dt, ((int64_t)b * P + p) * C + c));
+// dst[b][c][p] = src[b][p][c] (src viewed as (B, P, C)), 32x32 tiles through LDS so that both the read (along c) and
+// the write (along p) are coalesced; converts between fp32 and bf16 on the way.
+__global__ __launch_bounds__(256) void permute_pc_kernel(const void* __restrict__ src, int sd, int P, int C,
+                                                         void* __restrict__ dst, int dd) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32, b = blockIdx.z;
+  const int64_t base = (int64_t)b * P * C;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = p0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (p < P && c < C) ? load_as_f32(src, sd, base + (int64_t)p * C + c) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, p = p0 + tx;
+    if (p < P && c < C) store_from_f32(dst, dd, base + (int64_t)c * P + p, tile[tx][ty + 8 * i]);
   }
 }
 
@@ -101,11 +112,13 @@ extern "C" int gdm_col2im(const void* cols, int cols_dtype, int B, int H, int W,
   return GDM_OK;
 }
 
-extern "C" int gdm_permute_pc(const void* src, int dtype, int B, int P, int C, void* dst, void* stream) {
-  GDM_REQUIRE(src && dst && B > 0 && P > 0 && C > 0 && gdm_dtype_ok(dtype), "gdm_permute_pc: bad arguments");
-  const int64_t total = (int64_t)B * P * C;
-  hipLaunchKernelGGL(permute_pc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dtype, B, P, C,
-                     dst);
+extern "C" int gdm_permute_pc(const void* src, int src_dtype, int B, int P, int C, void* dst, int dst_dtype,
+                              void* stream) {
+  GDM_REQUIRE(src && dst && B > 0 && P > 0 && C > 0 && gdm_dtype_ok(src_dtype) && gdm_dtype_ok(dst_dtype),
+              "gdm_permute_pc: bad arguments");
+  GDM_REQUIRE(B <= 65535 && (C + 31) / 32 <= 65535, "gdm_permute_pc: extent too large");
+  hipLaunchKernelGGL(permute_pc_kernel, dim3((P + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, src,
+                     src_dtype, P, C, dst, dst_dtype);
   GDM_LAUNCH_OK("gdm_permute_pc");
   return GDM_OK;
 }

@@ -143,23 +143,49 @@ __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restri
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-// Fixed-order parallel sum of `nslabs` slabs of `width` floats: a 1024-thread workgroup owns 64 consecutive
-// elements; wave w adds slabs w, w+16, ... (coalesced 256-B rows), then the 16 partials are added in wave order.
-__global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict__ slabs, int nslabs, int width,
-                                                        float* __restrict__ out) {
+// =====================================================================================================================
+// Fixed-order two-level sum of `nslabs` slabs of `width` floats (deterministic replacement for float atomics).
+// Level 1: grid (width/64, groups): a 1024-thread workgroup owns 64 consecutive elements of one slab group; wave w adds
+// slabs w, w+16, ... of its group (coalesced 256-B rows), the 16 partials are added in wave order.  Level 2 adds the
+// group partials in order.
+// =====================================================================================================================
+__global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict__ slabs, int nslabs, int per_group,
+                                                        int width, float* __restrict__ out) {
   __shared__ float part[16][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
-  float s = 0.f;
-  if (i < width)
-    for (int k = wv; k < nslabs; k += 16) s += slabs[(int64_t)k * width + i];
-  part[wv][lane] = s;
+  const int k0 = blockIdx.y * per_group, k1 = min(nslabs, k0 + per_group);
+  float s0 = 0.f, s1 = 0.f;
+  if (i < width) {
+    int k = k0 + wv;
+    for (; k + 16 < k1; k += 32) {
+      s0 += slabs[(int64_t)k * width + i];
+      s1 += slabs[(int64_t)(k + 16) * width + i];
+    }
+    if (k < k1) s0 += slabs[(int64_t)k * width + i];
+  }
+  part[wv][lane] = s0 + s1;
   __syncthreads();
   if (wv == 0 && i < width) {
     float t = part[0][lane];
 #pragma unroll
     for (int w = 1; w < 16; ++w) t += part[w][lane];
-    out[i] = t;
+    out[(int64_t)blockIdx.y * width + i] = t;
+  }
+}
+
+// sums `nslabs` slabs into `result` (width floats) using `scratch` (>= slab_groups(nslabs) * width floats)
+inline int slab_groups(int nslabs) { return nslabs <= 64 ? 1 : (nslabs + 255) / 256 > 64 ? 64 : (nslabs + 255) / 256; }
+inline void launch_slab_sum(const float* slabs, int nslabs, int width, float* scratch, float* result, hipStream_t s) {
+  const int groups = slab_groups(nslabs);
+  const int per = (nslabs + groups - 1) / groups;
+  const unsigned gx = (unsigned)((width + 63) / 64);
+  if (groups == 1) {
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(gx, 1), dim3(1024), 0, s, slabs, nslabs, per, width, result);
+  } else {
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(gx, groups), dim3(1024), 0, s, slabs, nslabs, per, width, scratch);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(gx, 1), dim3(1024), 0, s, (const float*)scratch, groups, groups, width,
+                       result);
   }
 }
 
@@ -174,183 +200,110 @@ __global__ __launch_bounds__(128) void conv1_bwd_weight_final(const float* __res
 }
 
 // =====================================================================================================================
-// conv2 forward: Conv2d(16,32,k3,s1,p1) + ReLU + MaxPool2d(2), implicit GEMM.
-// Workgroup = (column super-tile, pooled row ph, image b): conv rows 2ph, 2ph+1, conv cols [c0, c0+128).
-// LDS: in_s[4][COLS+2][S16] (rows 2ph-1..2ph+2, cols c0-1..c0+128), w_s[32][KP] with k = tap*16 + ci.
-// Wave w owns conv cols [c0+32w, c0+32w+32): accumulators acc[mtile 2][dy 2][jx 2].
-// code2 byte: 0..3 argmax position (dy*2+dx), 4 = dead (pooled value is 0 after ReLU).
+// conv2 block.  Tile = ROWS (4) conv rows x COLS (128) conv columns of one image per 256-thread workgroup; wave w owns
+// columns [32w, 32w+32).  Activations/gradients around it are channels-last:
+//   p1, dp1 (B,H1,W1,16)   p2, dp2 (B,H2,W2,32)   code2 (B,H2,W2,32) uint8 (0..3 argmax position, 4 = ReLU-dead)
+// Weights are consumed from a pre-packed image (gdm_simnn_conv2_pack, rebuilt after every optimizer step):
+//   forward  image Wf[32][KPF]: k = tap*16 + ci                       (zero padded to the MFMA k granularity)
+//   backward image Wb[16][KPB]: k = tap'*32 + o with tap' = 8 - tap   (the flipped kernel of the data gradient)
 // =====================================================================================================================
+constexpr int ROWS = 4;
 template <typename T> struct C2 {
-  static constexpr int KP = sizeof(T) == 2 ? 168 : 146;  // weight row stride (elements); bf16 rows hold 160 k (padded)
-  static constexpr int S16 = Px<T>::S16;
-  static constexpr int IN_ELEMS = 4 * (COLS + 2) * S16;
-  static constexpr int W_ELEMS = 32 * KP;
+  static constexpr int KPF = sizeof(T) == 2 ? 168 : 146;
+  static constexpr int KPB = sizeof(T) == 2 ? 296 : 290;
+  static constexpr int WF_ELEMS = 32 * KPF, WB_ELEMS = 16 * KPB;
+  static constexpr int S16 = Px<T>::S16, S32 = Px<T>::S32;
+  static constexpr int WP = COLS + 2;
+  static constexpr int IN_ELEMS = (ROWS + 2) * WP * S16;     // p1 halo band
+  static constexpr int DCH_ELEMS = (ROWS + 2) * WP * S32;    // dc2 halo band (data gradient)
+  static constexpr int DC_ELEMS = ROWS * COLS * S32;         // dc2 band without halo (weight gradient)
 };
+constexpr int XW = 2 * COLS + 4;                             // x band row (floats) for the fused conv1 weight gradient
+constexpr int XROWS = 2 * ROWS + 1;
 
 template <typename T>
-__global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, int H1, int W1, int H2,
-                                                        int W2, T* __restrict__ p2, uint8_t* __restrict__ code2) {
-  constexpr int S16 = C2<T>::S16, KP = C2<T>::KP, WP = COLS + 2;
-  __shared__ __attribute__((aligned(16))) T smem[C2<T>::IN_ELEMS + C2<T>::W_ELEMS];
-  T* in_s = smem;
-  T* w_s = smem + C2<T>::IN_ELEMS;
-  const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
-  const int c0 = blockIdx.x * COLS, ph = blockIdx.y, b = blockIdx.z;
-
-  // ---- stage weights: w (32,16,3,3) -> w_s[o][tap*16+ci]
-  for (int i = t; i < 32 * (KP); i += 256) {
-    const int o = i / KP, k = i % KP;
+__global__ __launch_bounds__(256) void conv2_pack_kernel(const float* __restrict__ w, T* __restrict__ wf,
+                                                         T* __restrict__ wb) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < C2<T>::WF_ELEMS) {
+    const int o = i / C2<T>::KPF, k = i % C2<T>::KPF;
     float v = 0.f;
-    if (k < 144) { const int tap = k >> 4, ci = k & 15; v = w[(o * 16 + ci) * 9 + tap]; }
-    w_s[i] = from_f32<T>(v);
+    if (k < 144) v = w[(o * 16 + (k & 15)) * 9 + (k >> 4)];
+    wf[i] = from_f32<T>(v);
   }
-  // ---- stage input band (channels-last records; 16-B pieces, zero outside the image)
-  {
-    constexpr int PIECES = (sizeof(T) == 2) ? 2 : 4;   // 16-byte pieces per pixel record
-    constexpr int EPP = 16 / PIECES;                     // elements per piece
-    const T* src = p1 + (int64_t)b * H1 * W1 * 16;
-    for (int i = t; i < 4 * WP * PIECES; i += 256) {
-      const int piece = i % PIECES, pix = i / PIECES;
-      const int cl = pix % WP, rl = pix / WP;
-      const int r = 2 * ph - 1 + rl, c = c0 - 1 + cl;
-      T* dst = in_s + (rl * WP + cl) * S16 + piece * EPP;
-      if (r >= 0 && r < H1 && c >= 0 && c < W1) {
-        const T* s = src + ((int64_t)r * W1 + c) * 16 + piece * EPP;
-        if constexpr (sizeof(T) == 2) *(bf16x8*)dst = *(const bf16x8*)s;
-        else { const f32x4 v = *(const f32x4*)s; dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
-      } else {
-#pragma unroll
-        for (int e = 0; e < EPP; ++e) dst[e] = from_f32<T>(0.f);
-      }
-    }
+  if (i < C2<T>::WB_ELEMS) {
+    const int ci = i / C2<T>::KPB, k = i % C2<T>::KPB;
+    float v = 0.f;
+    if (k < 288) v = w[((k & 31) * 16 + ci) * 9 + (8 - (k >> 5))];
+    wb[i] = from_f32<T>(v);
   }
-  __syncthreads();
+}
 
-  f32x4 acc[2][2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][d][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int colb = 32 * wv + lr;  // local conv column of this lane for jx = 0
+template <typename T>
+__device__ __forceinline__ void copy_to_lds(T* __restrict__ dst, const T* __restrict__ src, int nelems) {
+  const int chunks = nelems * (int)sizeof(T) / 16;
+  for (int i = threadIdx.x; i < chunks; i += 256) ((f32x4*)dst)[i] = ((const f32x4*)src)[i];
+}
 
-  if constexpr (sizeof(T) == 2) {
+// p1 halo band (rows r_first .. r_first+NR-1, cols c_first .. c_first+WP-1) -> LDS [row][col][S16], zero outside
+template <typename T, int NR>
+__device__ __forceinline__ void stage_p1_band(const T* __restrict__ p1b, int H1, int W1, int r_first, int c_first,
+                                              T* __restrict__ in_s) {
+  constexpr int S16 = C2<T>::S16, WP = C2<T>::WP;
+  constexpr int PIECES = (sizeof(T) == 2) ? 2 : 4, EPP = 16 / PIECES;
+  for (int i = threadIdx.x; i < NR * WP * PIECES; i += 256) {
+    const int piece = i % PIECES, pix = i / PIECES;
+    const int cl = pix % WP, rl = pix / WP;
+    const int r = r_first + rl, c = c_first + cl;
+    T* dst = in_s + (rl * WP + cl) * S16 + piece * EPP;
+    if (r >= 0 && r < H1 && c >= 0 && c < W1) {
+      const T* s = p1b + ((int64_t)r * W1 + c) * 16 + piece * EPP;
+      if constexpr (sizeof(T) == 2) *(bf16x8*)dst = *(const bf16x8*)s;
+      else { const f32x4 v = *(const f32x4*)s; dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
+    } else {
 #pragma unroll
-    for (int ks = 0; ks < 5; ++ks) {
-      int tap = 2 * ks + (lg >> 1);
-      tap = tap > 8 ? 8 : tap;               // k >= 144: weights are zero, read any valid record
-      const int kh = tap / 3, kw = tap % 3;
-      bf16x8 a[2], bb[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8*)&w_s[(16 * i + lr) * KP + 32 * ks + 8 * lg];
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          bb[d][j] = *(const bf16x8*)&in_s[((d + kh) * WP + colb + 16 * j + kw) * S16 + 8 * (lg & 1)];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][d][j] = mfma16(a[i], bb[d][j], acc[i][d][j]);
-    }
-  } else {
-#pragma unroll 4
-    for (int ks = 0; ks < 36; ++ks) {
-      const int tap = ks >> 2, ci = 4 * (ks & 3) + lg;
-      const int kh = tap / 3, kw = tap % 3;
-      float a[2], bb[2][2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = w_s[(16 * i + lr) * KP + 4 * ks + lg];
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bb[d][j] = in_s[((d + kh) * WP + colb + 16 * j + kw) * S16 + ci];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][d][j] = mfma16(a[i], bb[d][j], acc[i][d][j]);
-    }
-  }
-  __syncthreads();  // in_s is dead from here: reuse it for the pooled output tile
-
-  // ---- epilogue: bias, ReLU, 2x2 max-pool (+code) -> out_s[32][64] / code_s[32][64] -> coalesced channel-major store
-  T* out_s = smem;                                  // 32*64 elements
-  uint8_t* code_s = (uint8_t*)(smem + 32 * 64);     // 32*64 bytes
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = 16 * i + 4 * lg + r;
-        const float bo = bias[o];
-        float v0 = acc[i][0][j][r] + bo, v1 = acc[i][1][j][r] + bo;
-        v0 = v0 > 0.f ? v0 : 0.f;
-        v1 = v1 > 0.f ? v1 : 0.f;
-        const float u0 = __shfl_xor(v0, 1, 64), u1 = __shfl_xor(v1, 1, 64);
-        if ((lr & 1) == 0) {
-          float best = v0; int bi = 0;
-          if (u0 > best) { best = u0; bi = 1; }
-          if (v1 > best) { best = v1; bi = 2; }
-          if (u1 > best) { best = u1; bi = 3; }
-          const int pwl = (32 * wv + 16 * j + lr) >> 1;
-          out_s[o * 64 + pwl] = from_f32<T>(best);
-          code_s[o * 64 + pwl] = best > 0.f ? (uint8_t)bi : (uint8_t)4;
-        }
-      }
-  __syncthreads();
-  {
-    const int pwl = t & 63;
-    const int pw = (c0 >> 1) + pwl;
-    if (pw < W2) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int o = (t >> 6) + 4 * q;
-        const int64_t gi = (((int64_t)b * 32 + o) * H2 + ph) * W2 + pw;
-        p2[gi] = out_s[o * 64 + pwl];
-        code2[gi] = code_s[o * 64 + pwl];
-      }
+      for (int e = 0; e < EPP; ++e) dst[e] = from_f32<T>(0.f);
     }
   }
 }
 
-// =====================================================================================================================
-// Shared by both conv2 backward kernels: rebuild rows [r_first, r_first+NR) x cols [cfirst, cfirst+NC) of the sparse
-// full-resolution gradient dc2[r][c][o] = (code2[o][r/2][c/2] == 2*(r&1)+(c&1)) ? dp2[o][r/2][c/2] : 0 in LDS as
-// [row][col][S32] records.  Each work item = (pooled row, pooled col, group of 8 channels); a lane keeps its
-// channel group (t & 3) so that it can also accumulate the bias gradient (sum of live dp2) in `bsum`.
-// =====================================================================================================================
+// Rebuild rows [r_first, r_first+NR) x cols [c_first, c_first+NC) of the sparse full-resolution gradient
+//   dc2[r][c][o] = (code2[r/2][c/2][o] == 2*(r&1)+(c&1)) ? dp2[r/2][c/2][o] : 0
+// in LDS as [row][col][S32] records.  r_first, c_first have the same parity as -HALO (both even or both odd handled).
+// Work item = (pooled pixel, group of 8 channels): one 16-B gradient load + one 8-B code load, up to four record
+// stores.  A lane keeps its channel group (t & 3), so it can also accumulate the bias gradient in `bsum`.
 template <typename T, int NR, int NC, bool WITH_BSUM>
 __device__ __forceinline__ void stage_dc2(const T* __restrict__ dp2b, const uint8_t* __restrict__ code2b, int H2,
                                           int W2, int r_first, int c_first, T* __restrict__ dc_s, float* bsum) {
-  constexpr int S32 = Px<T>::S32;
-  const int t = threadIdx.x;
-  const int og = t & 3;                                   // channels 8*og .. 8*og+7
-  const int pr_first = r_first >> 1;                      // arithmetic shift: floor for negatives
-  const int pc_first = c_first >> 1;
+  constexpr int S32 = C2<T>::S32;
+  const int t = threadIdx.x, og = t & 3;
+  const int pr_first = r_first >> 1, pc_first = c_first >> 1;           // arithmetic shift = floor
   const int npr = ((r_first + NR - 1) >> 1) - pr_first + 1;
   const int npc = ((c_first + NC - 1) >> 1) - pc_first + 1;
   for (int it = t >> 2; it < npr * npc; it += 64) {
     const int pcl = it % npc, prl = it / npc;
     const int pr = pr_first + prl, pc = pc_first + pcl;
-    const bool valid = pr >= 0 && pr < H2 && pc >= 0 && pc < W2;
     float g[8];
-    int cd[8];
+    uint64_t cd = 0x0404040404040404ull;
+    if (pr >= 0 && pr < H2 && pc >= 0 && pc < W2) {
+      const int64_t gi = (((int64_t)pr * W2 + pc) * 32) + 8 * og;
+      cd = *(const uint64_t*)(code2b + gi);
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 v = *(const bf16x8*)(dp2b + gi);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      g[e] = 0.f; cd[e] = 4;
-      if (valid) {
-        const int64_t gi = ((int64_t)(8 * og + e) * H2 + pr) * W2 + pc;
-        g[e] = to_f32(dp2b[gi]);
-        cd[e] = code2b[gi];
-        if (WITH_BSUM) bsum[e] += (cd[e] < 4) ? g[e] : 0.f;
+        for (int e = 0; e < 8; ++e) g[e] = (float)v[e];
+      } else {
+        const f32x4 v0 = *(const f32x4*)(dp2b + gi), v1 = *(const f32x4*)(dp2b + gi + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[e] = v0[e]; g[4 + e] = v1[e]; }
       }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) g[e] = 0.f;
+    }
+    if (WITH_BSUM) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bsum[e] += (((cd >> (8 * e)) & 0xff) < 4) ? g[e] : 0.f;
     }
 #pragma unroll
     for (int pos = 0; pos < 4; ++pos) {
@@ -360,64 +313,163 @@ __device__ __forceinline__ void stage_dc2(const T* __restrict__ dp2b, const uint
         if constexpr (sizeof(T) == 2) {
           bf16x8 v;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (__bf16)(cd[e] == pos ? g[e] : 0.f);
+          for (int e = 0; e < 8; ++e) v[e] = (__bf16)((int)((cd >> (8 * e)) & 0xff) == pos ? g[e] : 0.f);
           *(bf16x8*)dst = v;
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) dst[e] = cd[e] == pos ? g[e] : 0.f;
+          for (int e = 0; e < 8; ++e) dst[e] = (int)((cd >> (8 * e)) & 0xff) == pos ? g[e] : 0.f;
         }
       }
     }
   }
 }
 
-// =====================================================================================================================
-// conv2 backward (data): dp1[ih][iw][ci] = sum_{ah,aw,o} dc2[ih-1+ah][iw-1+aw][o] * w[o][ci][2-ah][2-aw]
-// Same tiling as the forward with CIN=32 (K = 288), M = 16 input channels; output written channels-last.
-// =====================================================================================================================
-template <typename T> struct D2 {
-  static constexpr int KP = sizeof(T) == 2 ? 296 : 290;   // 288 k + pad (bf16: 16-B aligned rows; f32: stride/2 odd)
-  static constexpr int S32 = Px<T>::S32;
-  static constexpr int DC_ELEMS = 4 * (COLS + 2) * S32;
-  static constexpr int W_ELEMS = 16 * KP;
-};
-
+// ---------------------------------------------------------------------------------------------------- conv2 forward
 template <typename T>
-__global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict__ dp2,
-                                                             const uint8_t* __restrict__ code2,
-                                                             const float* __restrict__ w, int H1, int W1, int H2,
-                                                             int W2, T* __restrict__ dp1) {
-  constexpr int S32 = D2<T>::S32, KP = D2<T>::KP, WP = COLS + 2;
+__global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1, const T* __restrict__ wf,
+                                                        const float* __restrict__ bias, int H1, int W1, int H2,
+                                                        int W2, T* __restrict__ p2, uint8_t* __restrict__ code2) {
+  constexpr int S16 = C2<T>::S16, KP = C2<T>::KPF, WP = C2<T>::WP;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-  T* dc_s = (T*)dyn_smem;
-  T* w_s = dc_s + D2<T>::DC_ELEMS;
+  T* in_s = (T*)dyn_smem;
+  T* w_s = in_s + C2<T>::IN_ELEMS;
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
-  const int c0 = blockIdx.x * COLS, rp = blockIdx.y, b = blockIdx.z;   // rows 2rp, 2rp+1 of the p1 geometry
-
-  // wT[ci][(ah*3+aw)*32 + o] = w[o][ci][2-ah][2-aw]
-  for (int i = t; i < 16 * KP; i += 256) {
-    const int ci = i / KP, k = i % KP;
-    float v = 0.f;
-    if (k < 288) { const int tap = k >> 5, o = k & 31; v = w[(o * 16 + ci) * 9 + (8 - tap)]; }
-    w_s[i] = from_f32<T>(v);
-  }
-  stage_dc2<T, 4, WP, false>(dp2 + (int64_t)b * 32 * H2 * W2, code2 + (int64_t)b * 32 * H2 * W2, H2, W2, 2 * rp - 1,
-                             c0 - 1, dc_s, nullptr);
+  const int c0 = blockIdx.x * COLS, rq = blockIdx.y, b = blockIdx.z;
+  copy_to_lds(w_s, wf, C2<T>::WF_ELEMS);
+  stage_p1_band<T, ROWS + 2>(p1 + (int64_t)b * H1 * W1 * 16, H1, W1, ROWS * rq - 1, c0 - 1, in_s);
   __syncthreads();
 
-  f32x4 acc[2][2];
+  f32x4 acc[2][ROWS][2];
 #pragma unroll
-  for (int d = 0; d < 2; ++d)
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int d = 0; d < ROWS; ++d)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][d][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int colb = 32 * wv + lr;
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      int tap = 2 * ks + (lg >> 1);
+      tap = tap > 8 ? 8 : tap;               // k >= 144: weights are zero, read any valid record
+      const int kh = tap / 3, kw = tap % 3;
+      bf16x8 a[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8*)&w_s[(16 * i + lr) * KP + 32 * ks + 8 * lg];
+#pragma unroll
+      for (int d = 0; d < ROWS; ++d)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bf16x8 bb = *(const bf16x8*)&in_s[((d + kh) * WP + colb + 16 * j + kw) * S16 + 8 * (lg & 1)];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][d][j] = mfma16(a[i], bb, acc[i][d][j]);
+        }
+    }
+  } else {
+#pragma unroll 2
+    for (int ks = 0; ks < 36; ++ks) {
+      const int tap = ks >> 2, ci = 4 * (ks & 3) + lg;
+      const int kh = tap / 3, kw = tap % 3;
+      float a[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = w_s[(16 * i + lr) * KP + 4 * ks + lg];
+#pragma unroll
+      for (int d = 0; d < ROWS; ++d)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float bb = in_s[((d + kh) * WP + colb + 16 * j + kw) * S16 + ci];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][d][j] = mfma16(a[i], bb, acc[i][d][j]);
+        }
+    }
+  }
+  // ---- epilogue on the accumulator tile: bias, ReLU, 2x2 max-pool + code; C layout: col (lr) = pixel,
+  //      row (4*lg + r) = channel within m-tile i  ->  an even lane owns 4 consecutive channels of one pooled pixel
+#pragma unroll
+  for (int pr = 0; pr < ROWS / 2; ++pr)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float best[4];
+        uint32_t codes = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float bo = bias[16 * i + 4 * lg + r];
+          float v0 = acc[i][2 * pr][j][r] + bo, v1 = acc[i][2 * pr + 1][j][r] + bo;
+          v0 = v0 > 0.f ? v0 : 0.f;
+          v1 = v1 > 0.f ? v1 : 0.f;
+          const float u0 = __shfl_xor(v0, 1, 64), u1 = __shfl_xor(v1, 1, 64);
+          float bv = v0; uint32_t bi = 0;
+          if (u0 > bv) { bv = u0; bi = 1; }
+          if (v1 > bv) { bv = v1; bi = 2; }
+          if (u1 > bv) { bv = u1; bi = 3; }
+          best[r] = bv;
+          codes |= (bv > 0.f ? bi : 4u) << (8 * r);
+        }
+        const int ph = (ROWS / 2) * rq + pr, pw = (c0 + colb + 16 * j) >> 1;
+        if ((lr & 1) == 0 && ph < H2 && pw < W2) {
+          const int64_t gi = ((((int64_t)b * H2 + ph) * W2 + pw) * 32) + 16 * i + 4 * lg;
+          if constexpr (sizeof(T) == 2) {
+            bf16x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (__bf16)best[r];
+            *(bf16x4*)(p2 + gi) = h;
+          } else {
+            *(f32x4*)(p2 + gi) = (f32x4){best[0], best[1], best[2], best[3]};
+          }
+          *(uint32_t*)(code2 + gi) = codes;
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------------- conv2 backward (data [+ conv1 dW])
+// dp1[ih][iw][ci] = sum_{ah,aw,o} dc2[ih-1+ah][iw-1+aw][o] * Wb[ci][(ah*3+aw)*32 + o]        (K = 288)
+// FUSE: instead of (or besides) writing dp1, route it through conv1's ReLU/pool code and contract it with the input
+// window held in LDS:  dW1[c][kh][kw] += live * dp1[c] * x[2ih+dy-1+kh][2iw+dx-1+kw],  db1[c] += live * dp1[c];
+// the workgroup's 80 partial sums go to one slab (summed in fixed order by slab_sum_kernel).
+template <typename T, bool FUSE>
+__global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict__ dp2,
+                                                             const uint8_t* __restrict__ code2,
+                                                             const T* __restrict__ wb, int H1, int W1, int H2, int W2,
+                                                             T* __restrict__ dp1, const uint64_t* __restrict__ code1,
+                                                             const float* __restrict__ x0, const float* __restrict__ x1,
+                                                             int bsplit, int H, int W, float* __restrict__ slabs) {
+  constexpr int S32 = C2<T>::S32, KP = C2<T>::KPB, WP = C2<T>::WP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  T* dc_s = (T*)dyn_smem;
+  T* w_s = dc_s + C2<T>::DCH_ELEMS;
+  float* x_s = (float*)(w_s + C2<T>::WB_ELEMS);          // FUSE only: [XROWS][XW]
+  float* red = x_s + XROWS * XW;                          // FUSE only: [4][80]
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
+  const int c0 = blockIdx.x * COLS, rq = blockIdx.y, b = blockIdx.z;
+
+  copy_to_lds(w_s, wb, C2<T>::WB_ELEMS);
+  stage_dc2<T, ROWS + 2, WP, false>(dp2 + (int64_t)b * H2 * W2 * 32, code2 + (int64_t)b * H2 * W2 * 32, H2, W2,
+                                    ROWS * rq - 1, c0 - 1, dc_s, nullptr);
+  if constexpr (FUSE) {
+    const float* xb = (b < bsplit) ? x0 + (int64_t)b * H * W : x1 + (int64_t)(b - bsplit) * H * W;
+    for (int i = t; i < XROWS * XW; i += 256) {
+      const int bc = i % XW, br = i / XW;
+      const int xr = 2 * ROWS * rq - 1 + br, xc = 2 * c0 - 1 + bc;
+      x_s[i] = (xr >= 0 && xr < H && xc >= 0 && xc < W) ? xb[(int64_t)xr * W + xc] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[ROWS][2];
+#pragma unroll
+  for (int d = 0; d < ROWS; ++d)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[d][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int colb = 32 * wv + lr;
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int ks = 0; ks < 9; ++ks) {           // one tap (32 channels) per k-step
+    for (int ks = 0; ks < 9; ++ks) {           // one (flipped) tap = 32 channels per k-step
       const int ah = ks / 3, aw = ks % 3;
       const bf16x8 a = *(const bf16x8*)&w_s[lr * KP + 32 * ks + 8 * lg];
 #pragma unroll
-      for (int d = 0; d < 2; ++d)
+      for (int d = 0; d < ROWS; ++d)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const bf16x8 bb = *(const bf16x8*)&dc_s[((d + ah) * WP + colb + 16 * j + aw) * S32 + 8 * lg];
@@ -425,13 +477,13 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
         }
     }
   } else {
-#pragma unroll 4
+#pragma unroll 2
     for (int ks = 0; ks < 72; ++ks) {
       const int tap = ks >> 3, o = 4 * (ks & 7) + lg;
       const int ah = tap / 3, aw = tap % 3;
       const float a = w_s[lr * KP + 4 * ks + lg];
 #pragma unroll
-      for (int d = 0; d < 2; ++d)
+      for (int d = 0; d < ROWS; ++d)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float bb = dc_s[((d + ah) * WP + colb + 16 * j + aw) * S32 + o];
@@ -439,41 +491,83 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
         }
     }
   }
-  // C layout: col (lr) = pixel, row (4*lg + r) = input channel -> 4 consecutive channels per lane, channels-last store
+  // C layout: col (lr) = pixel, row (4*lg + r) = input channel ci
+  if (dp1 != nullptr) {
 #pragma unroll
-  for (int d = 0; d < 2; ++d)
+    for (int d = 0; d < ROWS; ++d)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int ih = 2 * rp + d, iw = c0 + colb + 16 * j;
-      if (ih < H1 && iw < W1) {
-        T* dst = dp1 + (((int64_t)b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
-        if constexpr (sizeof(T) == 2) {
-          bf16x4 v;
+      for (int j = 0; j < 2; ++j) {
+        const int ih = ROWS * rq + d, iw = c0 + colb + 16 * j;
+        if (ih < H1 && iw < W1) {
+          T* dst = dp1 + (((int64_t)b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
+          if constexpr (sizeof(T) == 2) {
+            bf16x4 v;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[d][j][r];
-          *(bf16x4*)dst = v;
-        } else {
-          *(f32x4*)dst = acc[d][j];
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[d][j][r];
+            *(bf16x4*)dst = v;
+          } else {
+            *(f32x4*)dst = acc[d][j];
+          }
         }
       }
+  }
+  if constexpr (FUSE) {
+    float a1[4][4], bs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bs[r] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a1[r][q] = 0.f;
     }
+#pragma unroll
+    for (int d = 0; d < ROWS; ++d)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ih = ROWS * rq + d, cl = colb + 16 * j, iw = c0 + cl;
+        uint64_t code = 0;
+        if (ih < H1 && iw < W1) code = code1[((int64_t)b * H1 + ih) * W1 + iw];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * lg + r;
+          const float g = ((code >> (32 + c)) & 1) ? acc[d][j][r] : 0.f;
+          const int pos = (int)((code >> (2 * c)) & 3);
+          const float* xp = x_s + (2 * d + (pos >> 1)) * XW + 2 * cl + (pos & 1);
+          a1[r][0] = fmaf(g, xp[0], a1[r][0]);
+          a1[r][1] = fmaf(g, xp[1], a1[r][1]);
+          a1[r][2] = fmaf(g, xp[XW], a1[r][2]);
+          a1[r][3] = fmaf(g, xp[XW + 1], a1[r][3]);
+          bs[r] += g;
+        }
+      }
+    // reduce over the 16 lanes that share a channel group, then over the 4 waves (fixed order)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = a1[r][q];
+        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        if (lr == 0) red[wv * 80 + (4 * lg + r) * 4 + q] = v;
+      }
+      float v = bs[r];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+      if (lr == 0) red[wv * 80 + 64 + 4 * lg + r] = v;
+    }
+    __syncthreads();
+    if (t < 80) {
+      const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      slabs[blk * 80 + t] = ((red[t] + red[80 + t]) + red[160 + t]) + red[240 + t];
+    }
+  }
 }
 
-// =====================================================================================================================
-// conv2 backward (weights): dW2[o][ci][kh][kw] = sum_{b,r,c} dc2[r][c][o] * p1[r-1+kh][c-1+kw][ci];  db2[o] = sum dc2
-// GEMM with M = 32 (o), N = 9 taps x 16 ci, K = pixels.  A workgroup walks units (image, row pair, column
-// super-tile); per unit it stages dc2 rows (2 x 128 x 32) and the p1 halo band (4 x 130 x 16) in LDS as
+// -------------------------------------------------------------------------------------- conv2 backward (weights)
+// dW2[o][ci][kh][kw] = sum_{b,r,c} dc2[r][c][o] * p1[r-1+kh][c-1+kw][ci];  db2[o] = sum dc2
+// GEMM with M = 32 (o), N = 9 taps x 16 ci, K = pixels.  A workgroup walks units (image, row quad, column
+// super-tile); per unit it stages dc2 rows (4 x 128 x 32) and the p1 halo band (6 x 130 x 16) in LDS as
 // [pixel][channel] and each wave contracts its 32-column slice: bf16 reads both operands with the transposing
 // ds_read_b64_tr_b16 (the contraction index is the pixel, the LDS images are channel-contiguous).
 // Accumulators (2 x 9 tiles per wave) live in registers across all units, then waves are summed through LDS in fixed
-// order and the workgroup writes one slab; a second kernel sums the slabs in order (deterministic).
-// =====================================================================================================================
-template <typename T> struct W2c {
-  static constexpr int S16 = Px<T>::S16, S32 = Px<T>::S32;
-  static constexpr int DC_ELEMS = 2 * COLS * S32;
-  static constexpr int P_ELEMS = 4 * (COLS + 2) * S16;
-};
-
+// order and the workgroup writes one slab.
 __device__ __forceinline__ bf16x4 lds_tr16(const __bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
 }
@@ -484,10 +578,10 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
                                                                const T* __restrict__ p1, int B, int H1, int W1,
                                                                int H2, int W2, int n_ctiles, int n_units,
                                                                float* __restrict__ slabs) {
-  constexpr int S16 = W2c<T>::S16, S32 = W2c<T>::S32, WP = COLS + 2;
+  constexpr int S16 = C2<T>::S16, S32 = C2<T>::S32, WP = C2<T>::WP;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   T* dc_s = (T*)dyn_smem;
-  T* p_s = dc_s + W2c<T>::DC_ELEMS;
+  T* p_s = dc_s + C2<T>::DC_ELEMS;
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
   f32x4 acc[2][9];
 #pragma unroll
@@ -497,38 +591,20 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
   float bsum[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
-  const int nrp = (H1 + 1) / 2;
+  const int nrq = (H1 + ROWS - 1) / ROWS;
 
   for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
-    const int ct = u % n_ctiles, rp = (u / n_ctiles) % nrp, b = u / (n_ctiles * nrp);
+    const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq, b = u / (n_ctiles * nrq);
     const int c0 = ct * COLS;
     __syncthreads();   // previous unit's readers are done
-    stage_dc2<T, 2, COLS, true>(dp2 + (int64_t)b * 32 * H2 * W2, code2 + (int64_t)b * 32 * H2 * W2, H2, W2, 2 * rp, c0,
-                                dc_s, bsum);
-    {
-      constexpr int PIECES = (sizeof(T) == 2) ? 2 : 4, EPP = 16 / PIECES;
-      const T* src = p1 + (int64_t)b * H1 * W1 * 16;
-      for (int i = t; i < 4 * WP * PIECES; i += 256) {
-        const int piece = i % PIECES, pix = i / PIECES;
-        const int cl = pix % WP, rl = pix / WP;
-        const int r = 2 * rp - 1 + rl, c = c0 - 1 + cl;
-        T* dst = p_s + (rl * WP + cl) * S16 + piece * EPP;
-        if (r >= 0 && r < H1 && c >= 0 && c < W1) {
-          const T* s = src + ((int64_t)r * W1 + c) * 16 + piece * EPP;
-          if constexpr (sizeof(T) == 2) *(bf16x8*)dst = *(const bf16x8*)s;
-          else { const f32x4 v = *(const f32x4*)s; dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
-        } else {
-#pragma unroll
-          for (int e = 0; e < EPP; ++e) dst[e] = from_f32<T>(0.f);
-        }
-      }
-    }
+    stage_dc2<T, ROWS, COLS, true>(dp2 + (int64_t)b * H2 * W2 * 32, code2 + (int64_t)b * H2 * W2 * 32, H2, W2,
+                                   ROWS * rq, c0, dc_s, bsum);
+    stage_p1_band<T, ROWS + 2>(p1 + (int64_t)b * H1 * W1 * 16, H1, W1, ROWS * rq - 1, c0 - 1, p_s);
     __syncthreads();
-    // wave wv contracts conv cols [32wv, 32wv+32) of both rows
     if constexpr (sizeof(T) == 2) {
       const int q = lr >> 2, p = lr & 3;
 #pragma unroll
-      for (int d = 0; d < 2; ++d) {
+      for (int d = 0; d < ROWS; ++d) {
         const int cb = 32 * wv + 8 * lg;   // this lane group's 8 pixels: cols cb .. cb+7 of row d
         bf16x8 a[2];
 #pragma unroll
@@ -549,7 +625,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
       }
     } else {
 #pragma unroll 1
-      for (int d = 0; d < 2; ++d)
+      for (int d = 0; d < ROWS; ++d)
 #pragma unroll 2
         for (int ks = 0; ks < 8; ++ks) {
           const int cpix = 32 * wv + 4 * ks + lg;
@@ -582,7 +658,6 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
   float* slab = slabs + (int64_t)blockIdx.x * (4608 + 32);
   for (int i = t; i < 4608; i += 256) slab[i] = ((red[i] + red[4608 + i]) + red[2 * 4608 + i]) + red[3 * 4608 + i];
   __syncthreads();
-  // bias sums: lane keeps channel group (t&3); reduce the 64 lanes-with-same-group x 8 channels through LDS
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[t * 8 + e] = bsum[e];
   __syncthreads();
@@ -613,6 +688,11 @@ inline int conv1_slabs(int64_t total) {
 }
 inline int conv2w_blocks(int n_units) { return n_units < 512 ? n_units : 512; }
 
+template <typename K>
+inline void allow_lds(K kernel, size_t bytes) {
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------- C ABI
@@ -635,7 +715,7 @@ extern "C" int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* 
 
 extern "C" size_t gdm_simnn_conv1_bwd_weight_workspace_bytes(int B, int H, int W) {
   const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
-  return (size_t)(conv1_slabs(total) + 1) * 80 * sizeof(float);
+  return (size_t)(conv1_slabs(total) + 65) * 80 * sizeof(float);
 }
 
 extern "C" int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1, const float* x, int B, int H, int W,
@@ -652,57 +732,119 @@ extern "C" int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_bwd_weight_kernel<T>, dim3(nslabs), dim3(256), 0, s, (const T*)dp1, code1,
                                        x, B, H, W, H1, W1, (float*)workspace));
-  float* sums = (float*)workspace + (size_t)nslabs * 80;
-  hipLaunchKernelGGL(slab_sum_kernel, dim3(2), dim3(1024), 0, s, (const float*)workspace, nslabs, 80, sums);
+  float* scratch = (float*)workspace + (size_t)nslabs * 80;
+  float* sums = scratch + 64 * 80;
+  launch_slab_sum((const float*)workspace, nslabs, 80, scratch, sums, s);
   hipLaunchKernelGGL(conv1_bwd_weight_final, dim3(1), dim3(128), 0, s, (const float*)sums, dw, db, accumulate);
   GDM_LAUNCH_OK("gdm_simnn_conv1_bwd_weight");
   return GDM_OK;
 }
 
-extern "C" int gdm_simnn_conv2_fwd(const void* p1, const float* w, const float* bias, int B, int H1, int W1, void* p2,
+extern "C" size_t gdm_simnn_conv2_pack_bytes(int dtype) {
+  return dtype == GDM_BF16 ? (size_t)(C2<__bf16>::WF_ELEMS + C2<__bf16>::WB_ELEMS) * 2
+                           : (size_t)(C2<float>::WF_ELEMS + C2<float>::WB_ELEMS) * 4;
+}
+
+extern "C" int gdm_simnn_conv2_pack(const float* w, int dtype, void* pack, void* stream) {
+  GDM_REQUIRE(w && pack && gdm_dtype_ok(dtype), "gdm_simnn_conv2_pack: bad arguments");
+  GDM_REQUIRE(((uintptr_t)pack & 15) == 0, "gdm_simnn_conv2_pack: pack buffer must be 16-byte aligned");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(conv2_pack_kernel<T>, dim3((C2<T>::WF_ELEMS + 255) / 256), dim3(256), 0,
+                                       (hipStream_t)stream, w, (T*)pack, (T*)pack + C2<T>::WF_ELEMS));
+  GDM_LAUNCH_OK("gdm_simnn_conv2_pack");
+  return GDM_OK;
+}
+
+extern "C" int gdm_simnn_conv2_fwd(const void* p1, const void* pack, const float* bias, int B, int H1, int W1, void* p2,
                                    uint8_t* code2, int dtype, void* stream) {
-  GDM_REQUIRE(p1 && w && bias && p2 && code2, "gdm_simnn_conv2_fwd: null pointer");
+  GDM_REQUIRE(p1 && pack && bias && p2 && code2, "gdm_simnn_conv2_fwd: null pointer");
   GDM_REQUIRE(B > 0 && B <= 65535 && H1 >= 2 && W1 >= 2 && gdm_dtype_ok(dtype), "gdm_simnn_conv2_fwd: bad arguments");
   const int H2 = H1 / 2, W2 = W1 / 2;
-  GDM_REQUIRE(H2 <= 65535, "gdm_simnn_conv2_fwd: H too large");
-  dim3 grid((2 * W2 + COLS - 1) / COLS, H2, B);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(conv2_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)p1, w,
-                                       bias, H1, W1, H2, W2, (T*)p2, code2));
+  dim3 grid((2 * W2 + COLS - 1) / COLS, (2 * H2 + ROWS - 1) / ROWS, B);
+  GDM_REQUIRE(grid.y <= 65535, "gdm_simnn_conv2_fwd: H too large");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == GDM_BF16) {
+    const size_t sm = (size_t)(C2<__bf16>::IN_ELEMS + C2<__bf16>::WF_ELEMS) * 2;
+    hipLaunchKernelGGL(conv2_fwd_kernel<__bf16>, grid, dim3(256), sm, s, (const __bf16*)p1, (const __bf16*)pack, bias,
+                       H1, W1, H2, W2, (__bf16*)p2, code2);
+  } else {
+    const size_t sm = (size_t)(C2<float>::IN_ELEMS + C2<float>::WF_ELEMS) * 4;
+    allow_lds(conv2_fwd_kernel<float>, sm);
+    hipLaunchKernelGGL(conv2_fwd_kernel<float>, grid, dim3(256), sm, s, (const float*)p1, (const float*)pack, bias, H1,
+                       W1, H2, W2, (float*)p2, code2);
+  }
   GDM_LAUNCH_OK("gdm_simnn_conv2_fwd");
   return GDM_OK;
 }
 
-extern "C" int gdm_simnn_conv2_bwd_data(const void* dp2, const uint8_t* code2, const float* w, int B, int H1, int W1,
-                                        void* dp1, int dtype, void* stream) {
-  GDM_REQUIRE(dp2 && code2 && w && dp1, "gdm_simnn_conv2_bwd_data: null pointer");
-  GDM_REQUIRE(B > 0 && B <= 65535 && H1 >= 2 && W1 >= 2 && gdm_dtype_ok(dtype),
-              "gdm_simnn_conv2_bwd_data: bad arguments");
+namespace {
+template <typename T, bool FUSE>
+int launch_bwd_data(const void* dp2, const uint8_t* code2, const void* pack, int B, int H1, int W1, void* dp1,
+                    const uint64_t* code1, const float* x0, const float* x1, int bsplit, int H, int W, float* slabs,
+                    hipStream_t s) {
   const int H2 = H1 / 2, W2 = W1 / 2;
-  dim3 grid((W1 + COLS - 1) / COLS, (H1 + 1) / 2, B);
-  GDM_REQUIRE(grid.y <= 65535, "gdm_simnn_conv2_bwd_data: H too large");
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == GDM_BF16) {
-    const size_t sm = (size_t)(D2<__bf16>::DC_ELEMS + D2<__bf16>::W_ELEMS) * 2;
-    hipLaunchKernelGGL(conv2_bwd_data_kernel<__bf16>, grid, dim3(256), sm, s, (const __bf16*)dp2, code2, w, H1, W1, H2,
-                       W2, (__bf16*)dp1);
-  } else {
-    const size_t sm = (size_t)(D2<float>::DC_ELEMS + D2<float>::W_ELEMS) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv2_bwd_data_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)sm);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(conv2_bwd_data_kernel<float>, grid, dim3(256), sm, s, (const float*)dp2, code2, w, H1, W1, H2,
-                       W2, (float*)dp1);
-  }
+  dim3 grid((W1 + COLS - 1) / COLS, (H1 + ROWS - 1) / ROWS, B);
+  size_t sm = (size_t)(C2<T>::DCH_ELEMS + C2<T>::WB_ELEMS) * sizeof(T);
+  if (FUSE) sm += (size_t)(XROWS * XW + 4 * 80) * sizeof(float);
+  allow_lds(conv2_bwd_data_kernel<T, FUSE>, sm);
+  hipLaunchKernelGGL((conv2_bwd_data_kernel<T, FUSE>), grid, dim3(256), sm, s, (const T*)dp2, code2,
+                     (const T*)pack + C2<T>::WF_ELEMS, H1, W1, H2, W2, (T*)dp1, code1, x0, x1, bsplit, H, W, slabs);
   GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_data");
+  return GDM_OK;
+}
+}  // namespace
+
+extern "C" int gdm_simnn_conv2_bwd_data(const void* dp2, const uint8_t* code2, const void* pack, int B, int H1, int W1,
+                                        void* dp1, int dtype, void* stream) {
+  GDM_REQUIRE(dp2 && code2 && pack && dp1, "gdm_simnn_conv2_bwd_data: null pointer");
+  GDM_REQUIRE(B > 0 && B <= 65535 && H1 >= 2 && W1 >= 2 && H1 <= 65535 * ROWS && gdm_dtype_ok(dtype),
+              "gdm_simnn_conv2_bwd_data: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == GDM_BF16)
+    return launch_bwd_data<__bf16, false>(dp2, code2, pack, B, H1, W1, dp1, nullptr, nullptr, nullptr, 0, 0, 0,
+                                          nullptr, s);
+  return launch_bwd_data<float, false>(dp2, code2, pack, B, H1, W1, dp1, nullptr, nullptr, nullptr, 0, 0, 0, nullptr,
+                                       s);
+}
+
+extern "C" size_t gdm_simnn_conv2_bwd_fused_workspace_bytes(int B, int H1, int W1) {
+  const size_t nblocks = (size_t)B * ((H1 + ROWS - 1) / ROWS) * ((W1 + COLS - 1) / COLS);
+  return (nblocks + 65) * 80 * sizeof(float);
+}
+
+extern "C" int gdm_simnn_conv2_bwd_fused(const void* dp2, const uint8_t* code2, const void* pack, int B, int H1, int W1,
+                                         const uint64_t* code1, const float* x0, const float* x1, int bsplit, int H,
+                                         int W, void* dp1_or_null, float* dw1, float* db1, int dtype, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  GDM_REQUIRE(dp2 && code2 && pack && code1 && x0 && dw1 && db1, "gdm_simnn_conv2_bwd_fused: null pointer");
+  GDM_REQUIRE(B > 0 && B <= 65535 && gdm_dtype_ok(dtype), "gdm_simnn_conv2_bwd_fused: bad arguments");
+  GDM_REQUIRE(H1 == (H + 1) / 2 && W1 == (W + 1) / 2 && H1 >= 2 && W1 >= 2,
+              "gdm_simnn_conv2_bwd_fused: (H1,W1)=(%d,%d) does not belong to a %dx%d input", H1, W1, H, W);
+  GDM_REQUIRE(bsplit >= 0 && bsplit <= B && (bsplit == B || x1 != nullptr),
+              "gdm_simnn_conv2_bwd_fused: second input pointer missing");
+  if (!workspace || workspace_bytes < gdm_simnn_conv2_bwd_fused_workspace_bytes(B, H1, W1)) {
+    gdm_set_error("gdm_simnn_conv2_bwd_fused: workspace too small");
+    return GDM_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int nblocks = B * ((H1 + ROWS - 1) / ROWS) * ((W1 + COLS - 1) / COLS);
+  float* slabs = (float*)workspace;
+  int rc = dtype == GDM_BF16
+               ? launch_bwd_data<__bf16, true>(dp2, code2, pack, B, H1, W1, dp1_or_null, code1, x0, x1, bsplit, H, W,
+                                               slabs, s)
+               : launch_bwd_data<float, true>(dp2, code2, pack, B, H1, W1, dp1_or_null, code1, x0, x1, bsplit, H, W,
+                                              slabs, s);
+  if (rc != GDM_OK) return rc;
+  float* scratch = slabs + (size_t)nblocks * 80;
+  float* sums = scratch + 64 * 80;
+  launch_slab_sum(slabs, nblocks, 80, scratch, sums, s);
+  hipLaunchKernelGGL(conv1_bwd_weight_final, dim3(1), dim3(128), 0, s, (const float*)sums, dw1, db1, 0);
+  GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_fused");
   return GDM_OK;
 }
 
 extern "C" size_t gdm_simnn_conv2_bwd_weight_workspace_bytes(int B, int H1, int W1) {
-  const int n_units = B * ((H1 + 1) / 2) * ((W1 + COLS - 1) / COLS);
-  return (size_t)(conv2w_blocks(n_units) + 1) * (4608 + 32) * sizeof(float);
+  const int n_units = B * ((H1 + ROWS - 1) / ROWS) * ((W1 + COLS - 1) / COLS);
+  return (size_t)(conv2w_blocks(n_units) + 65) * (4608 + 32) * sizeof(float);
 }
 
 extern "C" int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2, const void* p1, int B, int H1, int W1,
@@ -716,36 +858,26 @@ extern "C" int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2,
   }
   const int H2 = H1 / 2, W2 = W1 / 2;
   const int n_ctiles = (W1 + COLS - 1) / COLS;
-  const int n_units = B * ((H1 + 1) / 2) * n_ctiles;
+  const int n_units = B * ((H1 + ROWS - 1) / ROWS) * n_ctiles;
   const int nblocks = conv2w_blocks(n_units);
   hipStream_t s = (hipStream_t)stream;
   const size_t red_bytes = (size_t)4 * 4608 * sizeof(float);
   if (dtype == GDM_BF16) {
-    size_t sm = (size_t)(W2c<__bf16>::DC_ELEMS + W2c<__bf16>::P_ELEMS) * 2;
+    size_t sm = (size_t)(C2<__bf16>::DC_ELEMS + C2<__bf16>::IN_ELEMS) * 2;
     if (sm < red_bytes) sm = red_bytes;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv2_bwd_weight_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)sm);
-      attr_set = true;
-    }
+    allow_lds(conv2_bwd_weight_kernel<__bf16>, sm);
     hipLaunchKernelGGL(conv2_bwd_weight_kernel<__bf16>, dim3(nblocks), dim3(256), sm, s, (const __bf16*)dp2, code2,
                        (const __bf16*)p1, B, H1, W1, H2, W2, n_ctiles, n_units, (float*)workspace);
   } else {
-    size_t sm = (size_t)(W2c<float>::DC_ELEMS + W2c<float>::P_ELEMS) * 4;
+    size_t sm = (size_t)(C2<float>::DC_ELEMS + C2<float>::IN_ELEMS) * 4;
     if (sm < red_bytes) sm = red_bytes;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv2_bwd_weight_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)sm);
-      attr_set = true;
-    }
+    allow_lds(conv2_bwd_weight_kernel<float>, sm);
     hipLaunchKernelGGL(conv2_bwd_weight_kernel<float>, dim3(nblocks), dim3(256), sm, s, (const float*)dp2, code2,
                        (const float*)p1, B, H1, W1, H2, W2, n_ctiles, n_units, (float*)workspace);
   }
-  float* sums = (float*)workspace + (size_t)nblocks * (4608 + 32);
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((4608 + 32 + 63) / 64), dim3(1024), 0, s, (const float*)workspace, nblocks,
-                     4608 + 32, sums);
+  float* scratch = (float*)workspace + (size_t)nblocks * (4608 + 32);
+  float* sums = scratch + (size_t)64 * (4608 + 32);
+  launch_slab_sum((const float*)workspace, nblocks, 4608 + 32, scratch, sums, s);
   hipLaunchKernelGGL(conv2_bwd_weight_final, dim3((4608 + 32 + 255) / 256), dim3(256), 0, s, (const float*)sums, dw,
                      db);
   GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_weight");

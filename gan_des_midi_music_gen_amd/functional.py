@@ -43,48 +43,69 @@ def _f32c(t):
 # ======================================================================================================================
 # Model 1 discriminator (GAN_DES/SIMNN.py:115-142)
 # ======================================================================================================================
-def simnn_disc_forward(x, w1, b1, w2, b2, wf1, bf1, wf2, bf2, dt):
-    """x (B,H,W) fp32 -> p (B,1) fp32 = sigmoid(fc2(relu(fc1(flatten(trunk(x)))))); returns (p, saved)."""
-    x = _f32c(x)
-    p1, code1 = ops.simnn_conv1_fwd(x, w1, b1, dt)
-    p2, code2 = ops.simnn_conv2_fwd(p1, w2, b2)
-    b = x.shape[0]
+def simnn_disc_prepare(w2, wf1, dt):
+    """Per-weight-version operands: conv2's packed MFMA images and fc1's weight permuted to the channels-last flatten
+    order of the feature map (and cast to the activation dtype).  (128, 32*P) -> (128, P*32)."""
+    pack = ops.simnn_conv2_pack(w2, dt)
+    n, k = wf1.shape
+    wf1p = ops.permute_pc(wf1, n, 32, k // 32, out_dtype=dt).view(n, k)
+    return pack, wf1p
+
+
+def simnn_disc_forward(x, w1, b1, pack, b2, wf1p, bf1, wf2, bf2, dt, trunk_out=None):
+    """x (B,H,W) fp32 -> p (B,1) fp32 = sigmoid(fc2(relu(fc1(flatten(trunk(x)))))); returns (p, saved).
+
+    pack, wf1p come from simnn_disc_prepare.  trunk_out = (p1, code1) buffers already filled by conv1 (2B batches)."""
+    if trunk_out is None:
+        x = _f32c(x)
+        p1, code1 = ops.simnn_conv1_fwd(x, w1, b1, dt)
+    else:
+        p1, code1 = trunk_out
+    p2, code2 = ops.simnn_conv2_fwd(p1, pack, b2)
+    b = p1.shape[0]
     flat = p2.view(b, -1)
-    if flat.shape[1] != wf1.shape[1]:
-        raise ValueError(f"Discriminator.fc1 expects {wf1.shape[1]} features but the {tuple(x.shape[1:])} input gives "
-                         f"{flat.shape[1]} (construct Discriminator(input_hw=...) for this geometry)")
-    h1 = ops.gemm(flat, wf1.t(), bias_n=bf1, act=ACT_RELU, compute=dt)
+    if flat.shape[1] != wf1p.shape[1]:
+        raise ValueError(f"Discriminator.fc1 expects {wf1p.shape[1]} features but this input gives {flat.shape[1]} "
+                         "(construct Discriminator(input_hw=...) for this geometry)")
+    h1 = ops.gemm(flat, wf1p.t(), bias_n=bf1, act=ACT_RELU, compute=dt)
     p = ops.gemm(h1, wf2.t(), bias_n=bf2, act=ACT_SIGMOID, compute=dt)
     return p, (x, p1, code1, flat, code2, h1, p)
 
 
-def simnn_disc_backward(saved, dz, w2, wf1, wf2, dt):
-    """dz (B,1) fp32 = d loss / d (pre-sigmoid logit).  Returns grads in parameter order (w1,b1,w2,b2,wf1,bf1,wf2,bf2)."""
+def simnn_disc_backward(saved, dz, pack, wf1p, wf2, dt, out=None, x_pair=None):
+    """dz (B,1) fp32 = d loss / d (pre-sigmoid logit).  Returns grads in parameter order
+    (w1,b1,w2,b2,wf1,bf1,wf2,bf2); ``out`` = 8 preallocated gradient tensors to fill instead.
+    x_pair = (x0, x1) when the batch is the concatenation of two input tensors (saved x is then ignored)."""
     x, p1, code1, flat, code2, h1, _p = saved
-    b = x.shape[0]
+    b = p1.shape[0]
+    o = out if out is not None else [None] * 8
     dz = dz.reshape(b, 1).contiguous()
-    dwf2 = ops.gemm(dz.t(), h1, compute=dt)                                   # (1,128)
-    dbf2 = ops.colsum(dz)
+    dwf2 = ops.gemm(dz.t(), h1, compute=dt, out=o[6])                         # (1,128)
+    dbf2 = ops.colsum(dz, out=o[7])
     dh1 = ops.gemm(dz, wf2, compute=dt)                                       # (B,128)
     dh1 = ops.act_bwd(dh1, h1, act=ACT_RELU)
-    dwf1 = ops.gemm(dh1.t(), flat, compute=dt)                                # (128,K)
-    dbf1 = ops.colsum(dh1)
-    dflat = ops.gemm(dh1, wf1, compute=dt, out_dtype=dt)                      # (B,K) in the activation dtype
+    n, k = wf1p.shape
+    dwf1p = ops.gemm(dh1.t(), flat, compute=dt)                               # (128, P*32) channels-last order
+    dwf1 = ops.permute_pc(dwf1p, n, k // 32, 32, out=o[4])                    # back to the parameter's (c, pix) order
+    dwf1 = dwf1.view(n, k)
+    dbf1 = ops.colsum(dh1, out=o[5])
+    dflat = ops.gemm(dh1, wf1p, compute=dt, out_dtype=dt)                     # (B,K) = dp2, channels-last
     h1s, w1s = p1.shape[1], p1.shape[2]
-    dp2 = dflat.view(b, 32, h1s // 2, w1s // 2)
-    dw2, db2 = ops.simnn_conv2_bwd_weight(dp2, code2, p1)
-    dp1 = ops.simnn_conv2_bwd_data(dp2, code2, w2, h1s, w1s)
-    dw1, db1 = ops.simnn_conv1_bwd_weight(dp1, code1, x)
+    dp2 = dflat.view(b, h1s // 2, w1s // 2, 32)
+    dw2, db2 = ops.simnn_conv2_bwd_weight(dp2, code2, p1, out=None if out is None else (o[2], o[3]))
+    x0, x1 = x_pair if x_pair is not None else (x, None)
+    dw1, db1, _ = ops.simnn_conv2_bwd_fused(dp2, code2, pack, code1, x0, x1, out=None if out is None else (o[0], o[1]))
     return dw1, db1, dw2, db2, dwf1, dbf1, dwf2, dbf2
 
 
 class SimnnDiscFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, wf1, bf1, wf2, bf2, dt):
-        p, saved = simnn_disc_forward(x, w1.detach(), b1.detach(), w2.detach(), b2.detach(), wf1.detach(),
-                                      bf1.detach(), wf2.detach(), bf2.detach(), dt)
+        pack, wf1p = simnn_disc_prepare(w2.detach(), wf1.detach(), dt)
+        p, saved = simnn_disc_forward(x, w1.detach(), b1.detach(), pack, b2.detach(), wf1p, bf1.detach(),
+                                      wf2.detach(), bf2.detach(), dt)
         ctx.saved = saved
-        ctx.weights = (w2.detach(), wf1.detach(), wf2.detach())
+        ctx.weights = (pack, wf1p, wf2.detach())
         ctx.dt = dt
         ctx.x_needs_grad = x.requires_grad
         return p
@@ -96,8 +117,8 @@ class SimnnDiscFn(torch.autograd.Function):
                                       "path (its inputs are data or detached bridge outputs, SIMNN.py:283,299-306)")
         p = ctx.saved[-1]
         dz = ops.act_bwd(dp.contiguous().float(), p, act=ACT_SIGMOID)
-        w2, wf1, wf2 = ctx.weights
-        grads = simnn_disc_backward(ctx.saved, dz, w2, wf1, wf2, ctx.dt)
+        pack, wf1p, wf2 = ctx.weights
+        grads = simnn_disc_backward(ctx.saved, dz, pack, wf1p, wf2, ctx.dt)
         return (None, *grads, None)
 
 

@@ -230,26 +230,65 @@ def simnn_conv1_fwd(x, w, bias, dt, out=None):
     return p1, code1
 
 
-def simnn_conv2_fwd(p1, w, bias):
-    _need_gpu(p1, w, bias)
-    assert p1.dim() == 4 and p1.shape[3] == 16 and p1.is_contiguous() and w.is_contiguous()
+def simnn_conv2_pack(w, dt):
+    """Packed MFMA operand images (forward + flipped backward) of conv2's weight; rebuild when w changes."""
+    _need_gpu(w)
+    assert w.shape == (32, 16, 3, 3) and w.dtype == torch.float32 and w.is_contiguous()
+    lib = _lib.load()
+    pack = torch.empty(lib.gdm_simnn_conv2_pack_bytes(dt), dtype=torch.uint8, device=w.device)
+    _call("gdm_simnn_conv2_pack", _p(w), dt, _p(pack), _stream())
+    return pack
+
+
+def simnn_conv2_fwd(p1, pack, bias):
+    """p1 (B,H1,W1,16) -> p2 (B,H2,W2,32) channels-last, code2 (B,H2,W2,32) uint8."""
+    _need_gpu(p1, pack, bias)
+    assert p1.dim() == 4 and p1.shape[3] == 16 and p1.is_contiguous()
     b, h1, w1, _ = p1.shape
     h2, w2 = h1 // 2, w1 // 2
-    p2 = torch.empty((b, 32, h2, w2), dtype=p1.dtype, device=p1.device)
-    code2 = torch.empty((b, 32, h2, w2), dtype=torch.uint8, device=p1.device)
-    _call("gdm_simnn_conv2_fwd", _p(p1), _p(w), _p(bias), b, h1, w1, _p(p2), _p(code2), gdm_dtype(p1),
-                                          _stream())
+    p2 = torch.empty((b, h2, w2, 32), dtype=p1.dtype, device=p1.device)
+    code2 = torch.empty((b, h2, w2, 32), dtype=torch.uint8, device=p1.device)
+    _call("gdm_simnn_conv2_fwd", _p(p1), _p(pack), _p(bias), b, h1, w1, _p(p2), _p(code2), gdm_dtype(p1), _stream())
     return p2, code2
 
 
-def simnn_conv2_bwd_data(dp2, code2, w, h1, w1):
-    _need_gpu(dp2, code2, w)
-    assert dp2.is_contiguous() and code2.is_contiguous() and w.is_contiguous()
+def simnn_conv2_bwd_data(dp2, code2, pack, h1, w1):
+    _need_gpu(dp2, code2, pack)
+    assert dp2.is_contiguous() and code2.is_contiguous() and dp2.shape[-1] == 32
     b = dp2.shape[0]
     dp1 = torch.empty((b, h1, w1, 16), dtype=dp2.dtype, device=dp2.device)
-    _call("gdm_simnn_conv2_bwd_data", _p(dp2), _p(code2), _p(w), b, h1, w1, _p(dp1), gdm_dtype(dp2),
-                                               _stream())
+    _call("gdm_simnn_conv2_bwd_data", _p(dp2), _p(code2), _p(pack), b, h1, w1, _p(dp1), gdm_dtype(dp2), _stream())
     return dp1
+
+
+def simnn_conv2_bwd_fused(dp2, code2, pack, code1, x0, x1=None, out=None, want_dp1=False):
+    """conv2 data gradient with conv1's weight gradient fused in (dp1 stays in registers).
+
+    x0 (B0,H,W) and optionally x1 (B1,H,W) are the inputs of samples [0,B0) and [B0,B0+B1).
+    Returns (dw1, db1, dp1 or None)."""
+    _need_gpu(dp2, code2, pack, code1, x0, x1)
+    assert dp2.is_contiguous() and code2.is_contiguous() and code1.is_contiguous() and x0.is_contiguous()
+    b = dp2.shape[0]
+    h, wd = x0.shape[1], x0.shape[2]
+    h1, w1 = code1.shape[1], code1.shape[2]
+    bsplit = x0.shape[0]
+    if x1 is not None:
+        assert x1.is_contiguous() and x1.shape[1:] == x0.shape[1:] and bsplit + x1.shape[0] == b
+    else:
+        assert bsplit == b
+    if out is not None:
+        dw, db = out
+        assert dw.numel() == 64 and db.numel() == 16 and dw.is_contiguous() and db.is_contiguous()
+    else:
+        dw = torch.empty((16, 1, 2, 2), dtype=torch.float32, device=x0.device)
+        db = torch.empty(16, dtype=torch.float32, device=x0.device)
+    dp1 = torch.empty((b, h1, w1, 16), dtype=dp2.dtype, device=dp2.device) if want_dp1 else None
+    lib = _lib.load()
+    nb = lib.gdm_simnn_conv2_bwd_fused_workspace_bytes(b, h1, w1)
+    ws = workspace(nb, x0.device)
+    _call("gdm_simnn_conv2_bwd_fused", _p(dp2), _p(code2), _p(pack), b, h1, w1, _p(code1), _p(x0), _p(x1), bsplit, h,
+          wd, _p(dp1), _p(dw), _p(db), gdm_dtype(dp2), _p(ws), nb, _stream())
+    return dw, db, dp1
 
 
 def simnn_conv2_bwd_weight(dp2, code2, p1, out=None):
@@ -312,10 +351,13 @@ def col2im(cols, *, b, h, w, c, kh, kw, stride, pad, oh, ow, out_dtype, planar=F
     return dst
 
 
-def permute_pc(src, b, p, c):
-    """(B, P, C) -> (B, C, P), same dtype (channels-last <-> channel-major)."""
-    _need_gpu(src)
+def permute_pc(src, b, p, c, out_dtype=None, out=None):
+    """(B, P, C) -> (B, C, P) with optional dtype conversion (channels-last <-> channel-major)."""
+    _need_gpu(src, out)
     assert src.is_contiguous() and src.numel() == b * p * c
-    dst = torch.empty((b, c, p), dtype=src.dtype, device=src.device)
-    _call("gdm_permute_pc", _p(src), gdm_dtype(src), b, p, c, _p(dst), _stream())
-    return dst
+    if out is None:
+        out = torch.empty((b, c, p), dtype=src.dtype if out_dtype is None else _TORCH_DT[out_dtype],
+                          device=src.device)
+    assert out.is_contiguous() and out.numel() == b * p * c
+    _call("gdm_permute_pc", _p(src), gdm_dtype(src), b, p, c, _p(out), gdm_dtype(out), _stream())
+    return out

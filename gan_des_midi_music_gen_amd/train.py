@@ -101,6 +101,11 @@ class SimnnTrainer(_TrainerBase):
                            disc.fc1.bias, disc.fc2.weight, disc.fc2.bias], lr, betas, eps, compute_dtype,
                           elide_dead_backward, process_group)
         self.last_generated = None
+        self._prepared = None      # (packed conv2 images, permuted fc1 weight) for the current weights
+
+    def invalidate_weights(self):
+        """Call after changing discriminator weights from outside (e.g. load_state_dict)."""
+        self._prepared = None
 
     def _gen_state(self):
         g = self.gen
@@ -116,7 +121,6 @@ class SimnnTrainer(_TrainerBase):
         Returns (disc_loss, gen_loss) as 1-element device tensors (this rank's batch means)."""
         dt = self.dt
         w1, b1, w2, b2, wf1, bf1, wf2, bf2 = self.d.views
-        g_w1, g_b1, g_w2, g_b2, g_wf1, g_bf1, g_wf2, g_bf2 = self.d.grad_views
         real = Fn._f32c(real)
         b, h, w = real.shape
         # --- generator forward (SIMNN.py:293-296); its output only feeds the (external) bridge
@@ -128,39 +132,33 @@ class SimnnTrainer(_TrainerBase):
         fake = Fn._f32c(fake.to(real.device))
         assert fake.shape == real.shape, (fake.shape, real.shape)
         # --- discriminator step on the 2B batch [real ; fake] (SIMNN.py:282-316)
+        if self._prepared is None:
+            self._prepared = Fn.simnn_disc_prepare(w2, wf1, dt)
+        pack, wf1p = self._prepared
         h1, w1s = (h + 1) // 2, (w + 1) // 2
         adt = ops.torch_dtype(dt)
         p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=real.device)
         code1 = torch.empty((2 * b, h1, w1s), dtype=torch.int64, device=real.device)
         ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
         ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
-        p2, code2 = ops.simnn_conv2_fwd(p1, w2, b2)
-        flat = p2.view(2 * b, -1)
-        hid = ops.gemm(flat, wf1.t(), bias_n=bf1, act=ops.ACT_RELU, compute=dt)
-        prob = ops.gemm(hid, wf2.t(), bias_n=bf2, act=ops.ACT_SIGMOID, compute=dt).view(-1)
+        prob, saved = Fn.simnn_disc_forward(None, w1, b1, pack, b2, wf1p, bf1, wf2, bf2, dt, trunk_out=(p1, code1))
+        prob = prob.view(-1)
         dz = torch.empty(2 * b, dtype=torch.float32, device=real.device)
         ops.bce_with_logits(prob[:b], 0.9, loss_out=self.loss_d, dx_out=dz[:b], fuse_sigmoid_backward=True)
         ops.bce_with_logits(prob[b:], 0.1, loss_out=self.loss_d, dx_out=dz[b:], fuse_sigmoid_backward=True,
                             accumulate_loss=True)
-        dz2 = dz.view(2 * b, 1)
-        ops.gemm(dz2.t(), hid, compute=dt, out=g_wf2)
-        ops.colsum(dz2, out=g_bf2)
-        dh = ops.act_bwd(ops.gemm(dz2, wf2, compute=dt), hid, act=ops.ACT_RELU)
-        ops.gemm(dh.t(), flat, compute=dt, out=g_wf1)
-        ops.colsum(dh, out=g_bf1)
-        dp2 = ops.gemm(dh, wf1, compute=dt, out_dtype=dt).view(2 * b, 32, h1 // 2, w1s // 2)
-        ops.simnn_conv2_bwd_weight(dp2, code2, p1, out=(g_w2, g_b2))
-        dp1 = ops.simnn_conv2_bwd_data(dp2, code2, w2, h1, w1s)
-        ops.simnn_conv1_bwd_weight(dp1[:b], code1[:b], real, out=(g_w1, g_b1))
-        ops.simnn_conv1_bwd_weight(dp1[b:], code1[b:], fake, out=(g_w1, g_b1), accumulate=True)
+        Fn.simnn_disc_backward(saved, dz, pack, wf1p, wf2, dt, out=self.d.grad_views, x_pair=(real, fake))
         self._reduce_and_step()
+        # weights changed: rebuild the packed conv2 images and the permuted fc1 operand once, use them for the G-step
+        # forward below AND for the next iteration's D-step forward
+        self._prepared = pack, wf1p = Fn.simnn_disc_prepare(w2, wf1, dt)
         # --- "generator" step (SIMNN.py:322-331): D forward on fake with the updated weights, label 1.0
-        prob_g, saved = Fn.simnn_disc_forward(fake, w1, b1, w2, b2, wf1, bf1, wf2, bf2, dt)
+        prob_g, saved = Fn.simnn_disc_forward(fake, w1, b1, pack, b2, wf1p, bf1, wf2, bf2, dt)
         if self.elide:
             ops.bce_with_logits(prob_g, 1.0, loss_out=self.loss_g, want_grad=False)
         else:
             _, dzg = ops.bce_with_logits(prob_g, 1.0, loss_out=self.loss_g, fuse_sigmoid_backward=True)
-            Fn.simnn_disc_backward(saved, dzg, w2, wf1, wf2, dt)   # dead values: only D's .grad, wiped next iteration
+            Fn.simnn_disc_backward(saved, dzg, pack, wf1p, wf2, dt)   # dead values: only D's .grad, wiped next iteration
         # gen_opt.step(): every generator .grad is None -> no-op
         self.iterations += 1
         return self.loss_d, self.loss_g

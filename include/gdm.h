@@ -96,16 +96,31 @@ int gdm_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n
  *   position (dy*2+dx, first maximum in scan order) of channel c, bit 32+c = channel c passes gradient
  *   (pooled value > 0); H1=(H+1)/2, W1=(W+1)/2.
  * conv2: Conv2d(16,32,k3,s1,p1)+ReLU+MaxPool2 fused, implicit GEMM on MFMA:
- *   p1 -> p2 (B,32,H2,W2) channel-major (the reference's flatten order, so fc1 is a plain GEMM), code2 (B,32,H2,W2)
- *   uint8 (0..3 = argmax position in scan order, 4 = ReLU-dead), H2=H1/2, W2=W1/2.                                */
+ *   p1 -> p2 (B,H2,W2,32) channels-last, code2 (B,H2,W2,32) uint8 (0..3 = argmax position in scan order,
+ *   4 = ReLU-dead), H2=H1/2, W2=W1/2.  The reference flattens channel-major (x.view(-1, 32*32*54), SIMNN.py:139);
+ *   the host keeps fc1's weight permuted to the channels-last order instead (gdm_permute_pc), which is the same
+ *   linear map.
+ * conv2 weights are consumed from a packed image built by gdm_simnn_conv2_pack (forward and flipped-backward MFMA
+ * operand layouts, in `dtype`); rebuild it whenever the weights change.                                            */
 int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* bias, int B, int H, int W, void* p1,
                         uint64_t* code1, int dtype, void* stream);
-int gdm_simnn_conv2_fwd(const void* p1, const float* w, const float* bias, int B, int H1, int W1, void* p2,
+size_t gdm_simnn_conv2_pack_bytes(int dtype);
+int gdm_simnn_conv2_pack(const float* w, int dtype, void* pack, void* stream);
+int gdm_simnn_conv2_fwd(const void* p1, const void* pack, const float* bias, int B, int H1, int W1, void* p2,
                         uint8_t* code2, int dtype, void* stream);
-/* backward of the conv2 block w.r.t. its input: dp2 (B,32,H2,W2) + code2 -> dp1 (B,H1,W1,16).  conv1's ReLU/pool
+/* backward of the conv2 block w.r.t. its input: dp2 (B,H2,W2,32) + code2 -> dp1 (B,H1,W1,16).  conv1's ReLU/pool
  * routing is not applied here; gdm_simnn_conv1_bwd_weight applies it through code1. */
-int gdm_simnn_conv2_bwd_data(const void* dp2, const uint8_t* code2, const float* w, int B, int H1, int W1, void* dp1,
+int gdm_simnn_conv2_bwd_data(const void* dp2, const uint8_t* code2, const void* pack, int B, int H1, int W1, void* dp1,
                              int dtype, void* stream);
+/* the same data gradient with conv1's weight gradient fused into its epilogue: dp1 is routed through code1 and
+ * contracted with the input windows while it is still in registers, so it never goes to HBM (dp1_or_null = NULL).
+ * Samples [0,bsplit) read their input from x0, samples [bsplit,B) from x1 (the 2B batch [real ; fake]).
+ * Writes dw1 (16,1,2,2), db1 (16).  workspace >= gdm_simnn_conv2_bwd_fused_workspace_bytes(B,H1,W1).              */
+size_t gdm_simnn_conv2_bwd_fused_workspace_bytes(int B, int H1, int W1);
+int gdm_simnn_conv2_bwd_fused(const void* dp2, const uint8_t* code2, const void* pack, int B, int H1, int W1,
+                              const uint64_t* code1, const float* x0, const float* x1, int bsplit, int H, int W,
+                              void* dp1_or_null, float* dw1, float* db1, int dtype, void* workspace,
+                              size_t workspace_bytes, void* stream);
 /* dW2 (32,16,3,3), db2 (32): deterministic slab reduction; workspace >= gdm_simnn_conv2_bwd_weight_workspace_bytes */
 size_t gdm_simnn_conv2_bwd_weight_workspace_bytes(int B, int H1, int W1);
 int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2, const void* p1, int B, int H1, int W1,
@@ -127,8 +142,9 @@ int gdm_im2col(const void* src, int src_dtype, int src_planar, int B, int H, int
 int gdm_col2im(const void* cols, int cols_dtype, int B, int H, int W, int C, int KH, int KW, int stride, int pad,
                int OH, int OW, void* dst, int dst_dtype, int dst_planar, void* stream);
 
-/* dst (B,C,P) = src (B,P,C) transposed per batch element (channels-last <-> channel-major flatten order). */
-int gdm_permute_pc(const void* src, int dtype, int B, int P, int C, void* dst, void* stream);
+/* dst (B,C,P) = src (B,P,C) transposed per batch element, with dtype conversion (channels-last <-> channel-major
+ * flatten order: activations, and fc1's weight / weight gradient viewed as (128, 32, H2*W2) <-> (128, H2*W2, 32)). */
+int gdm_permute_pc(const void* src, int src_dtype, int B, int P, int C, void* dst, int dst_dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -202,7 +202,7 @@ def _disc_trunk_ref(x, w1, b1, w2, b2):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
-@pytest.mark.parametrize("b,h,w", [(2, 128, 216), (3, 128, 256), (2, 16, 24), (1, 10, 300)])
+@pytest.mark.parametrize("b,h,w", [(2, 128, 216), (3, 128, 256), (2, 16, 24), (1, 10, 300), (2, 22, 30)])
 def test_simnn_conv_trunk_forward_backward(dt, b, h, w):
     g = torch.Generator().manual_seed(h * w + b)
     x = (torch.randn(b, h, w, generator=g) * 18 - 35).clamp(-80, 30)
@@ -212,57 +212,57 @@ def test_simnn_conv_trunk_forward_backward(dt, b, h, w):
     b2 = (torch.randn(32, generator=g) * 0.1).requires_grad_(True)
     a1, a2 = _disc_trunk_ref(x, w1, b1, w2, b2)
     rt = 3e-5 if dt == F32 else 2e-2
-    p1, code1 = ops.simnn_conv1_fwd(x.to(DEV), w1.detach().to(DEV), b1.detach().to(DEV), dt)
+    xd = x.to(DEV)
+    p1, code1 = ops.simnn_conv1_fwd(xd, w1.detach().to(DEV), b1.detach().to(DEV), dt)
     _close(p1.float().permute(0, 3, 1, 2), a1, 1e-5 if dt == F32 else 1e-2, "conv1+relu+pool")
-    if dt == BF16:
-        # continue the reference from the bf16-rounded activations the kernel actually consumed
-        a1 = p1.float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
-        a2 = F.max_pool2d(torch.relu(F.conv2d(a1, _rb(w2.detach()).requires_grad_(True), b2, padding=1)), 2, 2)
-    p2, code2 = ops.simnn_conv2_fwd(p1, w2.detach().to(DEV), b2.detach().to(DEV))
-    _close(p2, a2, rt, "conv2+relu+pool")
+    pack = ops.simnn_conv2_pack(w2.detach().to(DEV), dt)
+    p2, code2 = ops.simnn_conv2_fwd(p1, pack, b2.detach().to(DEV))
     assert int(code2.max().item()) <= 4
-    # ---- backward of the conv2 block for a given upstream gradient
     up = torch.randn(a2.shape, generator=g)
     if dt == F32:
+        _close(p2.permute(0, 3, 1, 2), a2, rt, "conv2+relu+pool")
         a1.retain_grad()
         (a2 * up).sum().backward()
-        ref_dp1, ref_dw2, ref_db2 = a1.grad, w2.grad, b2.grad
+        ref_dp1, ref_dw2, ref_db2, ref_dw1, ref_db1 = a1.grad, w2.grad, b2.grad, w1.grad, b1.grad
     else:
+        # continue the reference from the bf16-rounded activations / weights / gradients the kernels consume
+        a1r = p1.float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
         w2r = _rb(w2.detach()).requires_grad_(True)
         b2r = b2.detach().clone().requires_grad_(True)
-        a2b = F.max_pool2d(torch.relu(F.conv2d(a1, w2r, b2r, padding=1)), 2, 2)
+        a2b = F.max_pool2d(torch.relu(F.conv2d(a1r, w2r, b2r, padding=1)), 2, 2)
+        _close(p2.permute(0, 3, 1, 2), a2b, rt, "conv2+relu+pool")
         (a2b * _rb(up)).sum().backward()
-        ref_dp1, ref_dw2, ref_db2 = a1.grad, w2r.grad, b2r.grad
-    upd = up.to(DEV).to(ops.torch_dtype(dt)).contiguous()
+        ref_dp1, ref_dw2, ref_db2 = a1r.grad, w2r.grad, b2r.grad
+        # conv1's weight gradient given that dp1 (fp32 inside the fused kernel)
+        w1r = w1.detach().clone().requires_grad_(True)
+        b1r = b1.detach().clone().requires_grad_(True)
+        a1f, _ = _disc_trunk_ref(x, w1r, b1r, w2.detach(), b2.detach())
+        (a1f * ref_dp1).sum().backward()
+        ref_dw1, ref_db1 = w1r.grad, b1r.grad
+    upd = up.permute(0, 2, 3, 1).contiguous().to(DEV).to(ops.torch_dtype(dt))
     h1, w1d = p1.shape[1], p1.shape[2]
-    dp1 = ops.simnn_conv2_bwd_data(upd, code2, w2.detach().to(DEV), h1, w1d)
+    dp1 = ops.simnn_conv2_bwd_data(upd, code2, pack, h1, w1d)
     _close(dp1.float().permute(0, 3, 1, 2), ref_dp1, 5e-5 if dt == F32 else 2e-2, "conv2 bwd data")
     dw2, db2 = ops.simnn_conv2_bwd_weight(upd, code2, p1)
     _close(dw2, ref_dw2, 1e-4 if dt == F32 else 2e-2, "conv2 bwd weight")
     _close(db2, ref_db2, 1e-4 if dt == F32 else 2e-2, "conv2 bwd bias")
     dw2b, db2b = ops.simnn_conv2_bwd_weight(upd, code2, p1)
     assert torch.equal(dw2, dw2b) and torch.equal(db2, db2b), "slab reduction must be bit-reproducible"
-    # ---- conv1 weight gradient from a given dp1 (routing through code1)
-    if dt == F32:
-        w1.grad = None
-        b1.grad = None
-        up1 = torch.randn(a1.shape, generator=g)
-        a1f, _ = _disc_trunk_ref(x, w1, b1, w2.detach(), b2.detach())
-        (a1f * up1).sum().backward()
-        up1d = up1.permute(0, 2, 3, 1).contiguous().to(DEV)
-        dw1, db1 = ops.simnn_conv1_bwd_weight(up1d, code1, x.to(DEV))
-        _close(dw1, w1.grad, 1e-4, "conv1 bwd weight")
-        _close(db1, b1.grad, 1e-4, "conv1 bwd bias")
-    else:
-        up1 = torch.randn(b, 16, h1, w1d, generator=g)
-        w1r = w1.detach().clone().requires_grad_(True)
-        b1r = b1.detach().clone().requires_grad_(True)
-        a1f, _ = _disc_trunk_ref(x, w1r, b1r, w2.detach(), b2.detach())
-        (a1f * _rb(up1)).sum().backward()
-        up1d = up1.permute(0, 2, 3, 1).contiguous().to(DEV).to(torch.bfloat16)
-        dw1, db1 = ops.simnn_conv1_bwd_weight(up1d, code1, x.to(DEV))
-        _close(dw1, w1r.grad, 1e-3, "conv1 bwd weight (bf16 grads)")
-        _close(db1, b1r.grad, 1e-3, "conv1 bwd bias (bf16 grads)")
+    # ---- conv1 weight gradient: standalone kernel from the stored dp1, and fused into the data-gradient kernel
+    dw1, db1 = ops.simnn_conv1_bwd_weight(dp1, code1, xd)
+    _close(dw1, ref_dw1, 2e-4 if dt == F32 else 2e-2, "conv1 bwd weight (standalone)")
+    _close(db1, ref_db1, 2e-4 if dt == F32 else 2e-2, "conv1 bwd bias (standalone)")
+    dw1f, db1f, dp1f = ops.simnn_conv2_bwd_fused(upd, code2, pack, code1, xd, want_dp1=True)
+    _close(dw1f, ref_dw1, 2e-4 if dt == F32 else 2e-2, "conv1 bwd weight (fused)")
+    _close(db1f, ref_db1, 2e-4 if dt == F32 else 2e-2, "conv1 bwd bias (fused)")
+    assert torch.equal(dp1f, dp1)
+    if b >= 2:   # the 2B-batch form: two input tensors behind one gradient batch
+        dw1s, db1s, _ = ops.simnn_conv2_bwd_fused(upd, code2, pack, code1, xd[:1].contiguous(), xd[1:].contiguous())
+        assert torch.equal(dw1s, dw1f) and torch.equal(db1s, db1f)
+    # accumulate flag of the standalone kernel
+    dw1a, db1a = dw1.clone(), db1.clone()
+    ops.simnn_conv1_bwd_weight(dp1, code1, xd, out=(dw1a, db1a), accumulate=True)
+    _close(dw1a, 2 * dw1, 1e-6, "accumulate")
 
 
 @pytest.mark.parametrize("planar,c,hw,k,s,p", [(True, 2, (128, 50), 4, 2, 1), (False, 16, (64, 25), 4, 2, 1),
@@ -286,10 +286,12 @@ def test_im2col_col2im(planar, c, hw, k, s, p):
 
 
 def test_permute_pc():
-    x = torch.randn(3, 40, 32)
+    x = torch.randn(3, 45, 70)
     for dt in (torch.float32, torch.bfloat16):
-        got = ops.permute_pc(x.to(DEV).to(dt), 3, 40, 32)
+        got = ops.permute_pc(x.to(DEV).to(dt), 3, 45, 70)
         assert torch.equal(got.cpu(), x.to(dt).permute(0, 2, 1).contiguous())
+    got = ops.permute_pc(x.to(DEV), 3, 45, 70, out_dtype=BF16)
+    assert torch.equal(got.cpu(), x.permute(0, 2, 1).contiguous().to(torch.bfloat16))
 
 
 def test_cpu_tensor_is_rejected():

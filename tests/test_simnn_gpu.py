@@ -208,7 +208,7 @@ def test_full_size_properties(mode):
         parts = torch.cat([disc(x[:100]), disc(x[100:])])
         again = disc(x)
     assert torch.equal(full, again), "forward must be deterministic"
-    assert (full - parts).abs().max().item() <= (1e-6 if mode == "fp32" else 1e-6), "samples must be independent"
+    assert (full - parts).abs().max().item() <= (1e-5 if mode == "fp32" else 2e-3), "samples must be independent"
     assert torch.isfinite(full).all() and full.min() >= 0 and full.max() <= 1
 
     def grads(sl):
