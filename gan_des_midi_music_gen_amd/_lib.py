@@ -38,6 +38,8 @@ SIGNATURES = {
     "gdm_simnn_conv2_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
     "gdm_simnn_conv1_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I]),
     "gdm_simnn_conv1_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _P, _Z, _P]),
+    "gdm_simnn_head_workspace_bytes": (_Z, [_I]),
+    "gdm_simnn_head": (_I, [_P, _P, _P, _I, _I, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "gdm_im2col": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "gdm_col2im": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "gdm_permute_pc": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),

@@ -115,19 +115,47 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
       }
 }
 
+// Sums the split-K slabs in a fixed order (4 interleaved partial sums over z so that the loads pipeline), then applies
+// the epilogue.  VEC: 4 consecutive n per lane (N % 4 == 0, row-major C).
+template <bool VEC>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs g) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)g.M * g.N) return;
-  const int m = (int)(idx / g.N), n = (int)(idx % g.N);
-  float s = 0.f;
-  for (int z = 0; z < g.split_k; ++z) s += g.ws[(int64_t)z * g.M * g.N + idx];
-  gemm_epilogue_store(g, m, n, s);
+  const int64_t total = (int64_t)g.M * g.N;
+  const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1);
+  if (idx >= total) return;
+  if constexpr (VEC) {
+    f32x4 s[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 3 < g.split_k; z += 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] += *(const f32x4*)(g.ws + (int64_t)(z + q) * total + idx);
+    }
+    for (; z < g.split_k; ++z) s[0] += *(const f32x4*)(g.ws + (int64_t)z * total + idx);
+    const f32x4 v = (s[0] + s[1]) + (s[2] + s[3]);
+    const int m = (int)(idx / g.N), n = (int)(idx % g.N);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gemm_epilogue_store(g, m, n + r, v[r]);
+  } else {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 3 < g.split_k; z += 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q] += g.ws[(int64_t)(z + q) * total + idx];
+    }
+    for (; z < g.split_k; ++z) s[0] += g.ws[(int64_t)z * total + idx];
+    gemm_epilogue_store(g, (int)(idx / g.N), (int)(idx % g.N), (s[0] + s[1]) + (s[2] + s[3]));
+  }
 }
 
 int launch_splitk_reduce(const GemmArgs& g, hipStream_t s) {
   if (g.split_k > 1) {
     const int64_t total = (int64_t)g.M * g.N;
-    hipLaunchKernelGGL(gemm_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g);
+    if (g.N % 4 == 0) {
+      hipLaunchKernelGGL(gemm_splitk_reduce<true>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, g);
+    } else {
+      hipLaunchKernelGGL(gemm_splitk_reduce<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g);
+    }
     GDM_LAUNCH_OK("gdm_gemm(split-k reduce)");
   }
   return GDM_OK;

@@ -424,3 +424,128 @@ extern "C" int gdm_cast(const void* src, int src_dtype, void* dst, int dst_dtype
   GDM_LAUNCH_OK("gdm_cast");
   return GDM_OK;
 }
+
+// =====================================================================================================================
+// Model 1 discriminator head, forward + loss + backward in ONE single-workgroup launch (GAN_DES/SIMNN.py:140-141 and
+// the BCE terms at 289/311/329).  Replaces the N = 1 / M = 1 GEMMs (fc2 forward, dW_fc2, dh1), two BCE launches,
+// the ReLU backward and two bias column sums:
+//   z[b] = h1[b,:] . w2 + b2;  p[b] = sigmoid(z[b]);  loss = sum over the two label halves of mean BCEWithLogits(p, y)
+//   dz[b] = (sigmoid(p[b]) - y) / n_half * p(1-p)          (the reference feeds the sigmoid OUTPUT to a logits loss)
+//   dh1[b,j] = dz[b] * w2[j] * (h1[b,j] > 0);  dw2[j] = sum_b dz[b] h1[b,j];  db2 = sum_b dz[b];  db1[j] = sum_b dh1[b,j]
+// rows [0, n0) carry label y0, rows [n0, n) label y1 (n0 == n: a single label).  All reductions in fixed order.
+// =====================================================================================================================
+namespace {
+constexpr int HEAD_ROWS = 32;   // batch rows per workgroup
+// partial layout per workgroup: [0,128) dw2, [128,256) db1, [256] db2, [257] loss
+__global__ __launch_bounds__(256) void simnn_head_kernel(const float* __restrict__ h1, const float* __restrict__ w2,
+                                                         const float* __restrict__ b2, int n, int n0, float y0,
+                                                         float y1, float* __restrict__ prob, float* __restrict__ dh1,
+                                                         float* __restrict__ partials) {
+  __shared__ float dz_s[HEAD_ROWS], lt_s[HEAD_ROWS], part[2][256];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int r0 = blockIdx.x * HEAD_ROWS, r1 = min(n, r0 + HEAD_ROWS);
+  const float wa = w2[lane], wb = w2[lane + 64], bias = b2[0];
+  float hv[HEAD_ROWS / 4][2];
+#pragma unroll
+  for (int k = 0; k < HEAD_ROWS / 4; ++k) {       // all loads first
+    const int b = r0 + wv + 4 * k;
+    hv[k][0] = b < r1 ? h1[(int64_t)b * 128 + lane] : 0.f;
+    hv[k][1] = b < r1 ? h1[(int64_t)b * 128 + 64 + lane] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < HEAD_ROWS / 4; ++k) {
+    const int b = r0 + wv + 4 * k, bl = wv + 4 * k;
+    const float s = wave_sum(hv[k][0] * wa + hv[k][1] * wb);
+    if (lane == 0) {
+      float lt = 0.f, dz = 0.f;
+      if (b < r1) {
+        const float z = s + bias;
+        const float p = 1.0f / (1.0f + expf(-z));
+        const bool first = b < n0;
+        const float y = first ? y0 : y1;
+        const float cnt = (float)(first ? n0 : n - n0);
+        prob[b] = p;
+        lt = (fmaxf(p, 0.f) - p * y + log1pf(expf(-fabsf(p)))) / cnt;
+        dz = (1.0f / (1.0f + expf(-p)) - y) / cnt * p * (1.f - p);
+      }
+      lt_s[bl] = lt;
+      dz_s[bl] = dz;
+    }
+  }
+  __syncthreads();
+  float* po = partials + (int64_t)blockIdx.x * 258;
+  if (t == 0) {
+    float l = 0.f, sdz = 0.f;
+#pragma unroll
+    for (int b = 0; b < HEAD_ROWS; ++b) { l += lt_s[b]; sdz += dz_s[b]; }
+    po[256] = sdz;
+    po[257] = l;
+  }
+  // backward for this row slice: thread (grp = t / 128, j = t % 128) walks rows grp, grp+2, ...
+  const int j = t & 127, grp = t >> 7;
+  const float wj = w2[j];
+  float s_w = 0.f, s_b1 = 0.f;
+  float hh[HEAD_ROWS / 2];
+#pragma unroll
+  for (int k = 0; k < HEAD_ROWS / 2; ++k) {
+    const int b = r0 + grp + 2 * k;
+    hh[k] = b < r1 ? h1[(int64_t)b * 128 + j] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < HEAD_ROWS / 2; ++k) {
+    const int b = r0 + grp + 2 * k;
+    const float d = dz_s[grp + 2 * k];
+    const float g = hh[k] > 0.f ? d * wj : 0.f;
+    if (dh1 != nullptr && b < r1) dh1[(int64_t)b * 128 + j] = g;
+    s_w = fmaf(d, hh[k], s_w);
+    s_b1 += g;
+  }
+  part[0][t] = s_w;
+  part[1][t] = s_b1;
+  __syncthreads();
+  if (t < 128) {
+    po[t] = part[0][t] + part[0][128 + t];
+    po[128 + t] = part[1][t] + part[1][128 + t];
+  }
+}
+
+__global__ __launch_bounds__(320) void simnn_head_final(const float* __restrict__ partials, int groups,
+                                                        float* __restrict__ loss, int accumulate_loss,
+                                                        float* __restrict__ dw2, float* __restrict__ db2,
+                                                        float* __restrict__ db1) {
+  const int t = threadIdx.x;
+  if (t >= 258) return;
+  float s = 0.f;
+  for (int g = 0; g < groups; ++g) s += partials[(int64_t)g * 258 + t];
+  if (t == 257) loss[0] = (accumulate_loss ? loss[0] : 0.f) + s;
+  else if (dw2 != nullptr) {
+    if (t < 128) dw2[t] = s;
+    else if (t < 256) db1[t - 128] = s;
+    else db2[0] = s;
+  }
+}
+}  // namespace
+
+extern "C" size_t gdm_simnn_head_workspace_bytes(int n) {
+  return (size_t)((n + HEAD_ROWS - 1) / HEAD_ROWS) * 258 * sizeof(float);
+}
+
+extern "C" int gdm_simnn_head(const float* h1, const float* w2, const float* b2, int n, int n0, float y0, float y1,
+                              float* prob, float* loss, int accumulate_loss, float* dh1, float* dw2, float* db2,
+                              float* db1, void* workspace, size_t workspace_bytes, void* stream) {
+  GDM_REQUIRE(h1 && w2 && b2 && prob && loss, "gdm_simnn_head: null pointer");
+  GDM_REQUIRE(n > 0 && n <= 65536 && n0 > 0 && n0 <= n, "gdm_simnn_head: bad batch n=%d n0=%d", n, n0);
+  GDM_REQUIRE(dh1 == nullptr || (dw2 && db2 && db1), "gdm_simnn_head: gradient outputs missing");
+  if (!workspace || workspace_bytes < gdm_simnn_head_workspace_bytes(n)) {
+    gdm_set_error("gdm_simnn_head: workspace too small");
+    return GDM_EWORKSPACE;
+  }
+  const int groups = (n + HEAD_ROWS - 1) / HEAD_ROWS;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(simnn_head_kernel, dim3(groups), dim3(256), 0, s, h1, w2, b2, n, n0, y0, y1, prob, dh1,
+                     (float*)workspace);
+  hipLaunchKernelGGL(simnn_head_final, dim3(1), dim3(320), 0, s, (const float*)workspace, groups, loss,
+                     accumulate_loss, dh1 ? dw2 : nullptr, db2, db1);
+  GDM_LAUNCH_OK("gdm_simnn_head");
+  return GDM_OK;
+}

@@ -218,8 +218,7 @@ template <typename T> struct C2 {
   static constexpr int DCH_ELEMS = (ROWS + 2) * WP * S32;    // dc2 halo band (data gradient)
   static constexpr int DC_ELEMS = ROWS * COLS * S32;         // dc2 band without halo (weight gradient)
 };
-constexpr int XW = 2 * COLS + 4;                             // x band row (floats) for the fused conv1 weight gradient
-constexpr int XROWS = 2 * ROWS + 1;
+constexpr int XROWS = 2 * ROWS + 1;                          // input-window rows behind ROWS rows of the p1 geometry
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv2_pack_kernel(const float* __restrict__ w, T* __restrict__ wf,
@@ -269,37 +268,62 @@ __device__ __forceinline__ void stage_p1_band(const T* __restrict__ p1b, int H1,
 
 // Rebuild rows [r_first, r_first+NR) x cols [c_first, c_first+NC) of the sparse full-resolution gradient
 //   dc2[r][c][o] = (code2[r/2][c/2][o] == 2*(r&1)+(c&1)) ? dp2[r/2][c/2][o] : 0
-// in LDS as [row][col][S32] records.  r_first, c_first have the same parity as -HALO (both even or both odd handled).
-// Work item = (pooled pixel, group of 8 channels): one 16-B gradient load + one 8-B code load, up to four record
-// stores.  A lane keeps its channel group (t & 3), so it can also accumulate the bias gradient in `bsum`.
-template <typename T, int NR, int NC, bool WITH_BSUM>
-__device__ __forceinline__ void stage_dc2(const T* __restrict__ dp2b, const uint8_t* __restrict__ code2b, int H2,
-                                          int W2, int r_first, int c_first, T* __restrict__ dc_s, float* bsum) {
-  constexpr int S32 = C2<T>::S32;
+// in LDS as [row][col][S32] records.  HALO: the band starts one row/column before an even origin (r_first, c_first odd),
+// otherwise at an even origin.  Work item = (pooled pixel, group of 8 channels): one 16-B gradient load + one 8-B code
+// load, up to four record stores.  All loads of a lane are issued before the first record is expanded (one exposed
+// memory latency per tile instead of one per item).  A lane keeps its channel group (t & 3), so it can also
+// accumulate the bias gradient in `bsum`.
+template <typename T, int NR, int NC, bool HALO> struct DcStage {
+  static constexpr int NPR = HALO ? NR / 2 + 1 : NR / 2, NPC = HALO ? NC / 2 + 1 : NC / 2;
+  static constexpr int ITERS = (NPR * NPC + 63) / 64;
+  f32x4 g[ITERS][sizeof(T) == 2 ? 1 : 2];
+  uint64_t cd[ITERS];
+};
+
+template <typename T, int NR, int NC, bool HALO>
+__device__ __forceinline__ void dc2_load(DcStage<T, NR, NC, HALO>& st, const T* __restrict__ dp2b,
+                                         const uint8_t* __restrict__ code2b, int H2, int W2, int r_first,
+                                         int c_first) {
+  using S = DcStage<T, NR, NC, HALO>;
   const int t = threadIdx.x, og = t & 3;
   const int pr_first = r_first >> 1, pc_first = c_first >> 1;           // arithmetic shift = floor
-  const int npr = ((r_first + NR - 1) >> 1) - pr_first + 1;
-  const int npc = ((c_first + NC - 1) >> 1) - pc_first + 1;
-  for (int it = t >> 2; it < npr * npc; it += 64) {
-    const int pcl = it % npc, prl = it / npc;
-    const int pr = pr_first + prl, pc = pc_first + pcl;
-    float g[8];
-    uint64_t cd = 0x0404040404040404ull;
-    if (pr >= 0 && pr < H2 && pc >= 0 && pc < W2) {
+#pragma unroll
+  for (int k = 0; k < S::ITERS; ++k) {
+    const int it = (t >> 2) + 64 * k;
+    const int pr = pr_first + it / S::NPC, pc = pc_first + it % S::NPC;
+    st.cd[k] = 0x0404040404040404ull;
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(T) == 2 ? 1 : 2); ++q) st.g[k][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (it < S::NPR * S::NPC && pr >= 0 && pr < H2 && pc >= 0 && pc < W2) {
       const int64_t gi = (((int64_t)pr * W2 + pc) * 32) + 8 * og;
-      cd = *(const uint64_t*)(code2b + gi);
-      if constexpr (sizeof(T) == 2) {
-        const bf16x8 v = *(const bf16x8*)(dp2b + gi);
+      st.cd[k] = *(const uint64_t*)(code2b + gi);
+      st.g[k][0] = *(const f32x4*)(dp2b + gi);
+      if constexpr (sizeof(T) == 4) st.g[k][1] = *(const f32x4*)(dp2b + gi + 4);
+    }
+  }
+}
+
+template <typename T, int NR, int NC, bool HALO, bool WITH_BSUM>
+__device__ __forceinline__ void dc2_expand(const DcStage<T, NR, NC, HALO>& st, int r_first, int c_first,
+                                           T* __restrict__ dc_s, float* bsum) {
+  using S = DcStage<T, NR, NC, HALO>;
+  constexpr int S32 = C2<T>::S32;
+  const int t = threadIdx.x, og = t & 3;
+  const int pr_first = r_first >> 1, pc_first = c_first >> 1;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) g[e] = (float)v[e];
-      } else {
-        const f32x4 v0 = *(const f32x4*)(dp2b + gi), v1 = *(const f32x4*)(dp2b + gi + 4);
+  for (int k = 0; k < S::ITERS; ++k) {
+    const int it = (t >> 2) + 64 * k;
+    if (it >= S::NPR * S::NPC) continue;
+    const int pr = pr_first + it / S::NPC, pc = pc_first + it % S::NPC;
+    const uint64_t cd = st.cd[k];
+    float g[8];
+    if constexpr (sizeof(T) == 2) {
+      const bf16x8 v = *(const bf16x8*)&st.g[k][0];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { g[e] = v0[e]; g[4 + e] = v1[e]; }
-      }
+      for (int e = 0; e < 8; ++e) g[e] = (float)v[e];
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g[e] = 0.f;
+      for (int e = 0; e < 4; ++e) { g[e] = st.g[k][0][e]; g[4 + e] = st.g[k][1][e]; }
     }
     if (WITH_BSUM) {
 #pragma unroll
@@ -425,56 +449,83 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
 
 // ---------------------------------------------------------------------------------- conv2 backward (data [+ conv1 dW])
 // dp1[ih][iw][ci] = sum_{ah,aw,o} dc2[ih-1+ah][iw-1+aw][o] * Wb[ci][(ah*3+aw)*32 + o]        (K = 288)
+// Tile = 4 rows x 64 columns per 256-thread workgroup, wave w owns row w (4 MFMA column tiles): half the LDS of the
+// 128-column tile, so four workgroups (16 waves) share a CU and hide each other's load/expand phases.
 // FUSE: instead of (or besides) writing dp1, route it through conv1's ReLU/pool code and contract it with the input
 // window held in LDS:  dW1[c][kh][kw] += live * dp1[c] * x[2ih+dy-1+kh][2iw+dx-1+kw],  db1[c] += live * dp1[c];
 // the workgroup's 80 partial sums go to one slab (summed in fixed order by slab_sum_kernel).
+constexpr int BD_COLS = 64, BD_WP = BD_COLS + 2, BD_XW = 2 * BD_COLS + 4;
+template <typename T> struct BD {
+  static constexpr int DC_ELEMS = (ROWS + 2) * BD_WP * C2<T>::S32;
+  static constexpr size_t lds_bytes(bool fuse) {
+    return (size_t)(DC_ELEMS + C2<T>::WB_ELEMS) * sizeof(T) + (fuse ? (size_t)(XROWS * BD_XW + 4 * 80) * 4 : 0);
+  }
+};
+
 template <typename T, bool FUSE>
-__global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict__ dp2,
-                                                             const uint8_t* __restrict__ code2,
-                                                             const T* __restrict__ wb, int H1, int W1, int H2, int W2,
-                                                             T* __restrict__ dp1, const uint64_t* __restrict__ code1,
-                                                             const float* __restrict__ x0, const float* __restrict__ x1,
-                                                             int bsplit, int H, int W, float* __restrict__ slabs) {
-  constexpr int S32 = C2<T>::S32, KP = C2<T>::KPB, WP = C2<T>::WP;
+__global__ __launch_bounds__(256, 4) void conv2_bwd_data_kernel(const T* __restrict__ dp2,
+                                                                const uint8_t* __restrict__ code2,
+                                                                const T* __restrict__ wb, int H1, int W1, int H2,
+                                                                int W2, T* __restrict__ dp1,
+                                                                const uint64_t* __restrict__ code1,
+                                                                const float* __restrict__ x0,
+                                                                const float* __restrict__ x1, int bsplit, int H, int W,
+                                                                float* __restrict__ slabs) {
+  constexpr int S32 = C2<T>::S32, KP = C2<T>::KPB, WP = BD_WP, XW = BD_XW;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   T* dc_s = (T*)dyn_smem;
-  T* w_s = dc_s + C2<T>::DCH_ELEMS;
+  T* w_s = dc_s + BD<T>::DC_ELEMS;
   float* x_s = (float*)(w_s + C2<T>::WB_ELEMS);          // FUSE only: [XROWS][XW]
   float* red = x_s + XROWS * XW;                          // FUSE only: [4][80]
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
-  const int c0 = blockIdx.x * COLS, rq = blockIdx.y, b = blockIdx.z;
+  const int c0 = blockIdx.x * BD_COLS, rq = blockIdx.y, b = blockIdx.z;
+  const int ih = ROWS * rq + wv;                          // this wave's output row
 
-  copy_to_lds(w_s, wb, C2<T>::WB_ELEMS);
-  stage_dc2<T, ROWS + 2, WP, false>(dp2 + (int64_t)b * H2 * W2 * 32, code2 + (int64_t)b * H2 * W2 * 32, H2, W2,
-                                    ROWS * rq - 1, c0 - 1, dc_s, nullptr);
+  // ---- issue every global load of this tile first: gradient/code records, the input window, conv1's codes
+  DcStage<T, ROWS + 2, WP, true> st;
+  dc2_load(st, dp2 + (int64_t)b * H2 * W2 * 32, code2 + (int64_t)b * H2 * W2 * 32, H2, W2, ROWS * rq - 1, c0 - 1);
+  constexpr int XIT = (XROWS * XW + 255) / 256;
+  float xv[FUSE ? XIT : 1];
+  uint64_t codes[FUSE ? 4 : 1];
   if constexpr (FUSE) {
     const float* xb = (b < bsplit) ? x0 + (int64_t)b * H * W : x1 + (int64_t)(b - bsplit) * H * W;
-    for (int i = t; i < XROWS * XW; i += 256) {
+#pragma unroll
+    for (int k = 0; k < XIT; ++k) {
+      const int i = t + 256 * k;
       const int bc = i % XW, br = i / XW;
       const int xr = 2 * ROWS * rq - 1 + br, xc = 2 * c0 - 1 + bc;
-      x_s[i] = (xr >= 0 && xr < H && xc >= 0 && xc < W) ? xb[(int64_t)xr * W + xc] : 0.f;
+      xv[k] = (i < XROWS * XW && xr >= 0 && xr < H && xc >= 0 && xc < W) ? xb[(int64_t)xr * W + xc] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iw = c0 + 16 * j + lr;
+      codes[j] = (ih < H1 && iw < W1) ? code1[((int64_t)b * H1 + ih) * W1 + iw] : 0ull;
+    }
+  }
+  copy_to_lds(w_s, wb, C2<T>::WB_ELEMS);
+  dc2_expand<T, ROWS + 2, WP, true, false>(st, ROWS * rq - 1, c0 - 1, dc_s, nullptr);
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int k = 0; k < XIT; ++k) {
+      const int i = t + 256 * k;
+      if (i < XROWS * XW) x_s[i] = xv[k];
     }
   }
   __syncthreads();
 
-  f32x4 acc[ROWS][2];
+  f32x4 acc[4];
 #pragma unroll
-  for (int d = 0; d < ROWS; ++d)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[d][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int colb = 32 * wv + lr;
+  for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
     for (int ks = 0; ks < 9; ++ks) {           // one (flipped) tap = 32 channels per k-step
       const int ah = ks / 3, aw = ks % 3;
       const bf16x8 a = *(const bf16x8*)&w_s[lr * KP + 32 * ks + 8 * lg];
 #pragma unroll
-      for (int d = 0; d < ROWS; ++d)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const bf16x8 bb = *(const bf16x8*)&dc_s[((d + ah) * WP + colb + 16 * j + aw) * S32 + 8 * lg];
-          acc[d][j] = mfma16(a, bb, acc[d][j]);
-        }
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 bb = *(const bf16x8*)&dc_s[((wv + ah) * WP + 16 * j + lr + aw) * S32 + 8 * lg];
+        acc[j] = mfma16(a, bb, acc[j]);
+      }
     }
   } else {
 #pragma unroll 2
@@ -483,33 +534,29 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
       const int ah = tap / 3, aw = tap % 3;
       const float a = w_s[lr * KP + 4 * ks + lg];
 #pragma unroll
-      for (int d = 0; d < ROWS; ++d)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const float bb = dc_s[((d + ah) * WP + colb + 16 * j + aw) * S32 + o];
-          acc[d][j] = mfma16(a, bb, acc[d][j]);
-        }
+      for (int j = 0; j < 4; ++j) {
+        const float bb = dc_s[((wv + ah) * WP + 16 * j + lr + aw) * S32 + o];
+        acc[j] = mfma16(a, bb, acc[j]);
+      }
     }
   }
   // C layout: col (lr) = pixel, row (4*lg + r) = input channel ci
   if (dp1 != nullptr) {
 #pragma unroll
-    for (int d = 0; d < ROWS; ++d)
+    for (int j = 0; j < 4; ++j) {
+      const int iw = c0 + 16 * j + lr;
+      if (ih < H1 && iw < W1) {
+        T* dst = dp1 + (((int64_t)b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
+        if constexpr (sizeof(T) == 2) {
+          bf16x4 v;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ih = ROWS * rq + d, iw = c0 + colb + 16 * j;
-        if (ih < H1 && iw < W1) {
-          T* dst = dp1 + (((int64_t)b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
-          if constexpr (sizeof(T) == 2) {
-            bf16x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[d][j][r];
-            *(bf16x4*)dst = v;
-          } else {
-            *(f32x4*)dst = acc[d][j];
-          }
+          for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[j][r];
+          *(bf16x4*)dst = v;
+        } else {
+          *(f32x4*)dst = acc[j];
         }
       }
+    }
   }
   if constexpr (FUSE) {
     float a1[4][4], bs[4];
@@ -520,25 +567,22 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
       for (int q = 0; q < 4; ++q) a1[r][q] = 0.f;
     }
 #pragma unroll
-    for (int d = 0; d < ROWS; ++d)
+    for (int j = 0; j < 4; ++j) {
+      const int cl = 16 * j + lr;
+      const uint64_t code = codes[j];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ih = ROWS * rq + d, cl = colb + 16 * j, iw = c0 + cl;
-        uint64_t code = 0;
-        if (ih < H1 && iw < W1) code = code1[((int64_t)b * H1 + ih) * W1 + iw];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = 4 * lg + r;
-          const float g = ((code >> (32 + c)) & 1) ? acc[d][j][r] : 0.f;
-          const int pos = (int)((code >> (2 * c)) & 3);
-          const float* xp = x_s + (2 * d + (pos >> 1)) * XW + 2 * cl + (pos & 1);
-          a1[r][0] = fmaf(g, xp[0], a1[r][0]);
-          a1[r][1] = fmaf(g, xp[1], a1[r][1]);
-          a1[r][2] = fmaf(g, xp[XW], a1[r][2]);
-          a1[r][3] = fmaf(g, xp[XW + 1], a1[r][3]);
-          bs[r] += g;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const int c = 4 * lg + r;
+        const float g = ((code >> (32 + c)) & 1) ? acc[j][r] : 0.f;
+        const int pos = (int)((code >> (2 * c)) & 3);
+        const float* xp = x_s + (2 * wv + (pos >> 1)) * XW + 2 * cl + (pos & 1);
+        a1[r][0] = fmaf(g, xp[0], a1[r][0]);
+        a1[r][1] = fmaf(g, xp[1], a1[r][1]);
+        a1[r][2] = fmaf(g, xp[XW], a1[r][2]);
+        a1[r][3] = fmaf(g, xp[XW + 1], a1[r][3]);
+        bs[r] += g;
       }
+    }
     // reduce over the 16 lanes that share a channel group, then over the 4 waves (fixed order)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -597,9 +641,10 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
     const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq, b = u / (n_ctiles * nrq);
     const int c0 = ct * COLS;
     __syncthreads();   // previous unit's readers are done
-    stage_dc2<T, ROWS, COLS, true>(dp2 + (int64_t)b * H2 * W2 * 32, code2 + (int64_t)b * H2 * W2 * 32, H2, W2,
-                                   ROWS * rq, c0, dc_s, bsum);
+    DcStage<T, ROWS, COLS, false> st;
+    dc2_load(st, dp2 + (int64_t)b * H2 * W2 * 32, code2 + (int64_t)b * H2 * W2 * 32, H2, W2, ROWS * rq, c0);
     stage_p1_band<T, ROWS + 2>(p1 + (int64_t)b * H1 * W1 * 16, H1, W1, ROWS * rq - 1, c0 - 1, p_s);
+    dc2_expand<T, ROWS, COLS, false, true>(st, ROWS * rq, c0, dc_s, bsum);
     __syncthreads();
     if constexpr (sizeof(T) == 2) {
       const int q = lr >> 2, p = lr & 3;
@@ -782,9 +827,8 @@ int launch_bwd_data(const void* dp2, const uint8_t* code2, const void* pack, int
                     const uint64_t* code1, const float* x0, const float* x1, int bsplit, int H, int W, float* slabs,
                     hipStream_t s) {
   const int H2 = H1 / 2, W2 = W1 / 2;
-  dim3 grid((W1 + COLS - 1) / COLS, (H1 + ROWS - 1) / ROWS, B);
-  size_t sm = (size_t)(C2<T>::DCH_ELEMS + C2<T>::WB_ELEMS) * sizeof(T);
-  if (FUSE) sm += (size_t)(XROWS * XW + 4 * 80) * sizeof(float);
+  dim3 grid((W1 + BD_COLS - 1) / BD_COLS, (H1 + ROWS - 1) / ROWS, B);
+  const size_t sm = BD<T>::lds_bytes(FUSE);
   allow_lds(conv2_bwd_data_kernel<T, FUSE>, sm);
   hipLaunchKernelGGL((conv2_bwd_data_kernel<T, FUSE>), grid, dim3(256), sm, s, (const T*)dp2, code2,
                      (const T*)pack + C2<T>::WF_ELEMS, H1, W1, H2, W2, (T*)dp1, code1, x0, x1, bsplit, H, W, slabs);
@@ -807,7 +851,7 @@ extern "C" int gdm_simnn_conv2_bwd_data(const void* dp2, const uint8_t* code2, c
 }
 
 extern "C" size_t gdm_simnn_conv2_bwd_fused_workspace_bytes(int B, int H1, int W1) {
-  const size_t nblocks = (size_t)B * ((H1 + ROWS - 1) / ROWS) * ((W1 + COLS - 1) / COLS);
+  const size_t nblocks = (size_t)B * ((H1 + ROWS - 1) / ROWS) * ((W1 + BD_COLS - 1) / BD_COLS);
   return (nblocks + 65) * 80 * sizeof(float);
 }
 
@@ -826,7 +870,7 @@ extern "C" int gdm_simnn_conv2_bwd_fused(const void* dp2, const uint8_t* code2, 
     return GDM_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int nblocks = B * ((H1 + ROWS - 1) / ROWS) * ((W1 + COLS - 1) / COLS);
+  const int nblocks = B * ((H1 + ROWS - 1) / ROWS) * ((W1 + BD_COLS - 1) / BD_COLS);
   float* slabs = (float*)workspace;
   int rc = dtype == GDM_BF16
                ? launch_bwd_data<__bf16, true>(dp2, code2, pack, B, H1, W1, dp1_or_null, code1, x0, x1, bsplit, H, W,

@@ -52,8 +52,8 @@ def simnn_disc_prepare(w2, wf1, dt):
     return pack, wf1p
 
 
-def simnn_disc_forward(x, w1, b1, pack, b2, wf1p, bf1, wf2, bf2, dt, trunk_out=None):
-    """x (B,H,W) fp32 -> p (B,1) fp32 = sigmoid(fc2(relu(fc1(flatten(trunk(x)))))); returns (p, saved).
+def simnn_disc_features(x, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=None):
+    """x (B,H,W) fp32 -> h1 (B,128) fp32 = relu(fc1(flatten(trunk(x)))); returns (h1, saved).
 
     pack, wf1p come from simnn_disc_prepare.  trunk_out = (p1, code1) buffers already filled by conv1 (2B batches)."""
     if trunk_out is None:
@@ -68,33 +68,48 @@ def simnn_disc_forward(x, w1, b1, pack, b2, wf1p, bf1, wf2, bf2, dt, trunk_out=N
         raise ValueError(f"Discriminator.fc1 expects {wf1p.shape[1]} features but this input gives {flat.shape[1]} "
                          "(construct Discriminator(input_hw=...) for this geometry)")
     h1 = ops.gemm(flat, wf1p.t(), bias_n=bf1, act=ACT_RELU, compute=dt)
+    return h1, (x, p1, code1, flat, code2, h1)
+
+
+def simnn_disc_forward(x, w1, b1, pack, b2, wf1p, bf1, wf2, bf2, dt, trunk_out=None):
+    """... -> p (B,1) fp32 = sigmoid(fc2(h1)); returns (p, saved)."""
+    h1, saved = simnn_disc_features(x, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out)
     p = ops.gemm(h1, wf2.t(), bias_n=bf2, act=ACT_SIGMOID, compute=dt)
-    return p, (x, p1, code1, flat, code2, h1, p)
+    return p, saved + (p,)
 
 
-def simnn_disc_backward(saved, dz, pack, wf1p, wf2, dt, out=None, x_pair=None):
-    """dz (B,1) fp32 = d loss / d (pre-sigmoid logit).  Returns grads in parameter order
-    (w1,b1,w2,b2,wf1,bf1,wf2,bf2); ``out`` = 8 preallocated gradient tensors to fill instead.
-    x_pair = (x0, x1) when the batch is the concatenation of two input tensors (saved x is then ignored)."""
-    x, p1, code1, flat, code2, h1, _p = saved
+def simnn_disc_backward_from_dh1(saved, dh1, pack, wf1p, dt, out=None, x_pair=None):
+    """dh1 (B,128) fp32 = gradient w.r.t. fc1's pre-activation (already through the ReLU).
+
+    Returns (dw1, db1, dw2, db2, dwf1); ``out`` = the 8 gradient tensors in parameter order (only the first five
+    are written).  x_pair = (x0, x1) when the batch is the concatenation of two input tensors."""
+    x, p1, code1, flat, code2 = saved[:5]
     b = p1.shape[0]
     o = out if out is not None else [None] * 8
-    dz = dz.reshape(b, 1).contiguous()
-    dwf2 = ops.gemm(dz.t(), h1, compute=dt, out=o[6])                         # (1,128)
-    dbf2 = ops.colsum(dz, out=o[7])
-    dh1 = ops.gemm(dz, wf2, compute=dt)                                       # (B,128)
-    dh1 = ops.act_bwd(dh1, h1, act=ACT_RELU)
     n, k = wf1p.shape
     dwf1p = ops.gemm(dh1.t(), flat, compute=dt)                               # (128, P*32) channels-last order
-    dwf1 = ops.permute_pc(dwf1p, n, k // 32, 32, out=o[4])                    # back to the parameter's (c, pix) order
-    dwf1 = dwf1.view(n, k)
-    dbf1 = ops.colsum(dh1, out=o[5])
+    dwf1 = ops.permute_pc(dwf1p, n, k // 32, 32, out=o[4]).view(n, k)         # back to the parameter's (c, pix) order
     dflat = ops.gemm(dh1, wf1p, compute=dt, out_dtype=dt)                     # (B,K) = dp2, channels-last
     h1s, w1s = p1.shape[1], p1.shape[2]
     dp2 = dflat.view(b, h1s // 2, w1s // 2, 32)
     dw2, db2 = ops.simnn_conv2_bwd_weight(dp2, code2, p1, out=None if out is None else (o[2], o[3]))
     x0, x1 = x_pair if x_pair is not None else (x, None)
     dw1, db1, _ = ops.simnn_conv2_bwd_fused(dp2, code2, pack, code1, x0, x1, out=None if out is None else (o[0], o[1]))
+    return dw1, db1, dw2, db2, dwf1
+
+
+def simnn_disc_backward(saved, dz, pack, wf1p, wf2, dt, out=None, x_pair=None):
+    """dz (B,1) fp32 = d loss / d (pre-sigmoid logit).  Returns grads in parameter order
+    (w1,b1,w2,b2,wf1,bf1,wf2,bf2); ``out`` = 8 preallocated gradient tensors to fill instead."""
+    h1 = saved[5]
+    b = h1.shape[0]
+    o = out if out is not None else [None] * 8
+    dz = dz.reshape(b, 1).contiguous()
+    dwf2 = ops.gemm(dz.t(), h1, compute=dt, out=o[6])                         # (1,128)
+    dbf2 = ops.colsum(dz, out=o[7])
+    dh1 = ops.act_bwd(ops.gemm(dz, wf2, compute=dt), h1, act=ACT_RELU)        # (B,128)
+    dbf1 = ops.colsum(dh1, out=o[5])
+    dw1, db1, dw2, db2, dwf1 = simnn_disc_backward_from_dh1(saved, dh1, pack, wf1p, dt, out, x_pair)
     return dw1, db1, dw2, db2, dwf1, dbf1, dwf2, dbf2
 
 

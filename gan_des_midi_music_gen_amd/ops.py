@@ -86,12 +86,13 @@ def workspace(nbytes, device):
 
 
 def default_split_k(m, n, k, compute):
-    kt = 64 if compute == BF16 else 32
-    tiles = ((m + 63) // 64) * ((n + 63) // 64)
+    """Split K only when the output has too few tiles to occupy the 256 CUs; aim at ~256 workgroups."""
+    tile, kt = (128, 32) if compute == BF16 else (64, 32)
+    tiles = ((m + tile - 1) // tile) * ((n + tile - 1) // tile)
     ktiles = (k + kt - 1) // kt
-    if tiles >= 256 or ktiles < 16:
+    if tiles >= 128 or ktiles < 32:
         return 1
-    return max(1, min(ktiles // 8, (1024 + tiles - 1) // tiles))
+    return max(1, min(ktiles // 8, (256 + tiles - 1) // tiles))
 
 
 def gemm(a, b, *, bias_n=None, bias_m=None, act=ACT_NONE, slope=0.0, out_dtype=None, compute=F32, split_k=None,
@@ -327,6 +328,32 @@ def simnn_conv1_bwd_weight(dp1, code1, x, out=None, accumulate=False):
     _call("gdm_simnn_conv1_bwd_weight", _p(dp1), _p(code1), _p(x), b, h, wd, _p(dw), _p(db), gdm_dtype(dp1),
                                          1 if accumulate else 0, _p(ws), nb, _stream())
     return dw, db
+
+
+def simnn_head(h1, w2, b2, n0, y0, y1, *, loss_out, accumulate_loss=False, want_grad=True, grad_out=None):
+    """Fused fc2 + sigmoid + BCE(+backward) of model 1's discriminator head.
+
+    h1 (n,128) fp32; rows [0,n0) carry label y0, the rest y1.  grad_out = (dw2, db2, db1) views to fill.
+    Returns (prob (n,), dh1 (n,128) or None, (dw2, db2, db1) or None)."""
+    _need_gpu(h1, w2, b2, loss_out)
+    assert h1.dim() == 2 and h1.shape[1] == 128 and h1.is_contiguous() and h1.dtype == torch.float32
+    n = h1.shape[0]
+    prob = torch.empty(n, dtype=torch.float32, device=h1.device)
+    dh1 = dw2 = db2 = db1 = None
+    if want_grad:
+        dh1 = torch.empty_like(h1)
+        if grad_out is not None:
+            dw2, db2, db1 = grad_out
+            assert dw2.numel() == 128 and db2.numel() == 1 and db1.numel() == 128
+        else:
+            dw2 = torch.empty((1, 128), dtype=torch.float32, device=h1.device)
+            db2 = torch.empty(1, dtype=torch.float32, device=h1.device)
+            db1 = torch.empty(128, dtype=torch.float32, device=h1.device)
+    nb = _lib.load().gdm_simnn_head_workspace_bytes(n)
+    ws = workspace(nb, h1.device)
+    _call("gdm_simnn_head", _p(h1), _p(w2), _p(b2), n, n0, float(y0), float(y1), _p(prob), _p(loss_out),
+          1 if accumulate_loss else 0, _p(dh1), _p(dw2), _p(db2), _p(db1), _p(ws), nb, _stream())
+    return prob, dh1, ((dw2, db2, db1) if want_grad else None)
 
 
 # ------------------------------------------------------------------------------------------ patch lowering

@@ -141,24 +141,21 @@ class SimnnTrainer(_TrainerBase):
         code1 = torch.empty((2 * b, h1, w1s), dtype=torch.int64, device=real.device)
         ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
         ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
-        prob, saved = Fn.simnn_disc_forward(None, w1, b1, pack, b2, wf1p, bf1, wf2, bf2, dt, trunk_out=(p1, code1))
-        prob = prob.view(-1)
-        dz = torch.empty(2 * b, dtype=torch.float32, device=real.device)
-        ops.bce_with_logits(prob[:b], 0.9, loss_out=self.loss_d, dx_out=dz[:b], fuse_sigmoid_backward=True)
-        ops.bce_with_logits(prob[b:], 0.1, loss_out=self.loss_d, dx_out=dz[b:], fuse_sigmoid_backward=True,
-                            accumulate_loss=True)
-        Fn.simnn_disc_backward(saved, dz, pack, wf1p, wf2, dt, out=self.d.grad_views, x_pair=(real, fake))
+        hid, saved = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1, code1))
+        gv = self.d.grad_views
+        # fc2 + sigmoid + both BCE terms (labels 0.9 / 0.1, SIMNN.py:284-311) + head backward: one launch
+        _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 0.9, 0.1, loss_out=self.loss_d, grad_out=(gv[6], gv[7], gv[5]))
+        Fn.simnn_disc_backward_from_dh1(saved, dh, pack, wf1p, dt, out=gv, x_pair=(real, fake))
         self._reduce_and_step()
         # weights changed: rebuild the packed conv2 images and the permuted fc1 operand once, use them for the G-step
         # forward below AND for the next iteration's D-step forward
         self._prepared = pack, wf1p = Fn.simnn_disc_prepare(w2, wf1, dt)
         # --- "generator" step (SIMNN.py:322-331): D forward on fake with the updated weights, label 1.0
-        prob_g, saved = Fn.simnn_disc_forward(fake, w1, b1, pack, b2, wf1p, bf1, wf2, bf2, dt)
-        if self.elide:
-            ops.bce_with_logits(prob_g, 1.0, loss_out=self.loss_g, want_grad=False)
-        else:
-            _, dzg = ops.bce_with_logits(prob_g, 1.0, loss_out=self.loss_g, fuse_sigmoid_backward=True)
-            Fn.simnn_disc_backward(saved, dzg, pack, wf1p, wf2, dt)   # dead values: only D's .grad, wiped next iteration
+        hid, saved = Fn.simnn_disc_features(fake, w1, b1, pack, b2, wf1p, bf1, dt)
+        _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 1.0, 1.0, loss_out=self.loss_g, want_grad=not self.elide)
+        if not self.elide:
+            # dead values: gen_loss.backward() only fills D's .grad, which the next zero_grad() wipes (SIMNN.py:330, 282)
+            Fn.simnn_disc_backward_from_dh1(saved, dh, pack, wf1p, dt)
         # gen_opt.step(): every generator .grad is None -> no-op
         self.iterations += 1
         return self.loss_d, self.loss_g

@@ -131,6 +131,17 @@ int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1, const flo
                                float* dw, float* db, int dtype, int accumulate, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/* head of model 1's discriminator, forward + loss + backward in one launch (SIMNN.py:140-141, 289/311/329):
+ * h1 (n,128) fp32 = relu(fc1) -> prob (n) = sigmoid(fc2), loss[0] (+)= sum over the two label halves of the batch
+ * means of BCEWithLogits(prob, y) (rows [0,n0) label y0, rows [n0,n) label y1; the sigmoid OUTPUT is fed to the
+ * logits loss exactly like the reference does), and if dh1 != NULL the gradients dh1 (n,128) (already through fc1's
+ * ReLU), dw2 (128), db2 (1), db1 (128 = column sums of dh1).  Row slices of 32 are reduced per workgroup, slices are
+ * summed in order by a second launch.  workspace >= gdm_simnn_head_workspace_bytes(n).                              */
+size_t gdm_simnn_head_workspace_bytes(int n);
+int gdm_simnn_head(const float* h1, const float* w2, const float* b2, int n, int n0, float y0, float y1, float* prob,
+                   float* loss, int accumulate_loss, float* dh1, float* dw2, float* db2, float* db1, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
 /* ---- generic convolution lowering helpers (model 2 discriminator, model 1 generator) ----------------------------
  * im2col for Conv2d fwd / dW and col2im (gather form, deterministic) for Conv2d dX and ConvTranspose2d fwd.
  * Activations are channels-last (B,H,W,C) unless `src_planar` (NCHW fp32 input planes, e.g. the piano-roll).

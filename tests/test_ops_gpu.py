@@ -122,6 +122,33 @@ def test_bce_with_logits():
         _close(dz, z.grad, 1e-5, "bce dz (fused sigmoid)")
 
 
+@pytest.mark.parametrize("n,n0,y0,y1", [(4, 2, 0.9, 0.1), (512, 256, 0.9, 0.1), (256, 256, 1.0, 1.0), (77, 30, 0.0, 1.0)])
+def test_simnn_head_fused_forward_loss_backward(n, n0, y0, y1):
+    g = torch.Generator().manual_seed(n)
+    h_pre = torch.randn(n, 128, generator=g, requires_grad=True)
+    w2 = (torch.randn(1, 128, generator=g) * 0.2).requires_grad_(True)
+    b2 = torch.randn(1, generator=g).requires_grad_(True)
+    h1 = torch.relu(h_pre)
+    p = torch.sigmoid(F.linear(h1, w2, b2)).reshape(-1)
+    loss = F.binary_cross_entropy_with_logits(p[:n0], torch.full((n0,), y0))
+    if n0 < n:
+        loss = loss + F.binary_cross_entropy_with_logits(p[n0:], torch.full((n - n0,), y1))
+    loss.backward()
+    lo = torch.full((1,), 123.0, device=DEV)
+    prob, dh1, (dw2, db2, db1) = ops.simnn_head(h1.detach().to(DEV), w2.detach().to(DEV), b2.detach().to(DEV), n0, y0,
+                                                y1, loss_out=lo)
+    assert abs(lo.item() - loss.item()) < 2e-6 * max(1, abs(loss.item()))
+    _close(prob, p, 1e-6, "head prob")
+    _close(dh1, h_pre.grad, 2e-5, "head dh1 (through ReLU)")
+    _close(dw2, w2.grad, 2e-5, "head dw2")
+    _close(db2, b2.grad, 2e-5, "head db2")
+    _close(db1, h_pre.grad.sum(0), 2e-5, "head db1")
+    lo2 = torch.full((1,), 1.5, device=DEV)
+    ops.simnn_head(h1.detach().to(DEV), w2.detach().to(DEV), b2.detach().to(DEV), n0, y0, y1, loss_out=lo2,
+                   accumulate_loss=True, want_grad=False)
+    assert abs(lo2.item() - 1.5 - loss.item()) < 1e-5
+
+
 def test_adam_matches_torch_optim():
     g = torch.Generator().manual_seed(4)
     for n, lr, betas in ((1000, 2e-5, (0.5, 0.999)), (21041, 0.01, (0.9, 0.999)), (7, 1e-3, (0.9, 0.99))):
