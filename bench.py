@@ -29,20 +29,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32 (spec; 155 measured)
 
-# dominant kernel per workload/dtype and its ALGORITHMIC bytes / flops per sample (derivation in DESIGN.md section 5)
+# dominant kernel (by total time in profiles/r01_*_kernel_stats.csv) per workload and its ALGORITHMIC bytes / flops per
+# sample (derivation in DESIGN.md section 5)
 def dominant_kernel(workload, dtype, hw, t):
-    if workload == "simnn":
-        h1, w1 = (hw[0] + 1) // 2, (hw[1] + 1) // 2
-        h2, w2 = h1 // 2, w1 // 2
-        esz = 2 if dtype == "bf16" else 4
-        # conv2 forward: read p1 (H1*W1*16), write p2 (32*H2*W2), activations only
-        return {"name": "gdm_simnn_conv2_fwd", "bytes_per_sample": (h1 * w1 * 16 + 32 * h2 * w2) * esz,
-                "flops_per_sample": 2.0 * h1 * w1 * 32 * 144}
     esz = 2 if dtype == "bf16" else 4
+    if workload == "simnn":
+        h, w = hw
+        h1, w1 = (h + 1) // 2, (w + 1) // 2
+        h2, w2 = h1 // 2, w1 // 2
+        # fused conv2 data-gradient + conv1 weight-gradient kernel: reads the pooled gradient dp2 and its codes,
+        # conv1's codes and the input window; writes nothing per sample (80 partial sums per workgroup)
+        nbytes = h2 * w2 * 32 * esz + h2 * w2 * 32 + h1 * w1 * 8 + h * w * 4
+        return {"name": "gdm_simnn_conv2_bwd_fused", "kernel": "conv2_bwd_data_kernel<FUSE> (gdm_simnn_conv2_bwd_fused)",
+                "bytes_per_sample": nbytes, "flops_per_sample": 2.0 * h1 * w1 * 16 * 288}
     oh2, ow2 = 128 // 4, t // 4
-    # model 2: the conv2 GEMM of DiscriminatorCNN (im2col rows x 256 -> 32 channels)
-    return {"name": "gdm_gemm", "bytes_per_sample": (oh2 * ow2 * 256 + oh2 * ow2 * 32) * esz,
-            "flops_per_sample": 2.0 * oh2 * ow2 * 256 * 32}
+    # model 2: the GEMMs of DiscriminatorCNN (im2col rows x 256 -> 32 channels is the largest)
+    return {"name": "gdm_gemm", "kernel": "gemm kernels (all gdm_gemm launches pooled)",
+            "bytes_per_sample": (oh2 * ow2 * 256 + oh2 * ow2 * 32) * esz, "flops_per_sample": 2.0 * oh2 * ow2 * 256 * 32}
 
 
 def parse():
@@ -62,16 +65,12 @@ def parse():
 
 
 def setup_dist(n):
-    import torch.distributed as dist
+    from gan_des_midi_music_gen_amd import dp
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if n > 1 or world > 1:
         if world != n:
             raise SystemExit(f"--gpus {n} needs torchrun with {n} ranks (WORLD_SIZE={world})")
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        return dist.get_rank(), world, local
+        return dp.init_from_env("nccl")
     torch.cuda.set_device(0)
     return 0, 1, 0
 
@@ -200,18 +199,18 @@ def main():
         torch.cuda.synchronize()
         avg_ms, launches = ops.timed_durations_ms()
         ops.time_entry_point(None)
-        # model 1: the timed entry point runs on the 2B batch (D step) and on B (G step): average samples per launch
         if args.workload == "simnn":
-            samples_per_launch = (2 * args.batch + args.batch) / 2.0
+            # the timed entry point runs on the 2B batch (D step) and, in faithful mode, on B (the dead backward)
+            samples_per_launch = 2.0 * args.batch if args.mode == "elided" else 1.5 * args.batch
             achieved = dk["bytes_per_sample"] * samples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                        "kernel": "conv2_fwd_kernel (gdm_simnn_conv2_fwd)", "avg_launch_ms": round(avg_ms, 4),
-                        "launches_timed": launches}
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dk["kernel"],
+                        "algorithmic_bytes_per_launch": int(dk["bytes_per_sample"] * samples_per_launch),
+                        "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
         else:
             roofline = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                        "traffic": None, "kernel": "gemm_kernel (all gdm_gemm launches pooled)",
-                        "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
+                        "traffic": None, "kernel": dk["kernel"], "avg_launch_ms": round(avg_ms, 4),
+                        "launches_timed": launches}
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if roofline and os.path.exists(tfile):
             try:

@@ -15,11 +15,10 @@ Generators are never updated by the reference loops (no gradient crosses the DES
 running statistics move, once (model 1) or twice (model 2) per iteration.
 """
 import torch
-import torch.distributed as dist
 
+from . import dp
 from . import functional as Fn
 from . import ops
-from .ops import BF16, F32
 
 
 class FlatBuffers:
@@ -28,9 +27,7 @@ class FlatBuffers:
     def __init__(self, params, extra=0):
         params = [p for p in params]
         assert params, "no parameters"
-        dev = params[0].device
-        if dev.type != "cuda":
-            raise ops.GdmError("training runs on a HIP device only: move the modules with .to('cuda') first")
+        dev = params[0].device     # the buffers can be laid out anywhere; the fused step itself needs a HIP device
         self.params = params
         self.numel = sum(p.numel() for p in params)
         self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
@@ -60,29 +57,22 @@ class FlatBuffers:
                       grad_scale)
 
 
-def _world():
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_world_size()
-    return 1
-
-
 class _TrainerBase:
     def _init_common(self, d_params, lr, betas, eps, compute_dtype, elide_dead_backward, process_group):
         self.dt = Fn.get_compute_dtype() if compute_dtype is None else Fn._NAMES[compute_dtype]
         self.lr, self.betas, self.eps = lr, betas, eps
         self.elide = elide_dead_backward
         self.pg = process_group
-        self.world = _world() if process_group is None else dist.get_world_size(process_group)
+        self.world = dp.world_size(process_group)
         self.d = FlatBuffers(d_params, extra=4)        # extra[0] = disc_loss (rides the all-reduce), [1] = gen_loss
         self.loss_d = self.d.extra[0:1]
         self.loss_g = self.d.extra[1:2]
         self.iterations = 0
 
     def _reduce_and_step(self):
-        if self.world > 1:
-            # one flat bucket: every D gradient + the local disc_loss mean; SUM here, 1/world folded into Adam
-            dist.all_reduce(self.d.bucket[: self.d.numel + 1], op=dist.ReduceOp.SUM, group=self.pg)
-        self.d.adam(self.lr, self.betas, self.eps, grad_scale=1.0 / self.world)
+        # one flat bucket: every D gradient + the local disc_loss mean; SUM here, 1/world folded into Adam
+        scale = dp.allreduce_bucket_(self.d.bucket, self.d.numel + 1, self.pg)
+        self.d.adam(self.lr, self.betas, self.eps, grad_scale=scale)
 
     def disc_loss_value(self):
         return self.loss_d.item() / self.world

@@ -1,0 +1,94 @@
+"""CPU, world_size 2 over gloo: the data-parallel exchange (flat bucket of discriminator gradients + loss scalar,
+SUM all-reduce, 1/world scale) reproduces the single-process result on the global batch.
+
+Gradients come from the CPU oracle here (the HIP kernels need a GPU); what is under test is the product's bucket
+layout (train.FlatBuffers), dp.allreduce_bucket_, dp.shard_bounds and the mean-of-means identity the trainers rely
+on.  The GPU path runs the same code with the bucket on the device and backend "nccl" (RCCL).
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gan_des_midi_music_gen_amd import dp, synthetic
+from gan_des_midi_music_gen_amd.train import FlatBuffers
+from oracle import simnn as osn, steps as ost
+
+HW = (16, 24)
+GLOBAL_B = 4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _local_grads(disc, real, fake):
+    b = real.shape[0]
+    loss = ost.bce_with_logits(disc(real).reshape(-1), torch.full((b,), 0.9)) + \
+        ost.bce_with_logits(disc(fake).reshape(-1), torch.full((b,), 0.1))
+    grads = torch.autograd.grad(loss, list(disc.parameters()))
+    return loss.detach(), grads
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    r, w, _ = dp.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    disc = osn.Discriminator(input_hw=HW).apply(osn.weights_init)       # identical replica on every rank
+    real, fake, _ = synthetic.simnn_inputs(GLOBAL_B, HW, seed=42)
+    lo, hi = dp.shard_bounds(GLOBAL_B, world, rank)
+    fb = FlatBuffers(list(disc.parameters()), extra=4)
+    loss, grads = _local_grads(disc, real[lo:hi], fake[lo:hi])
+    for gv, g in zip(fb.grad_views, grads):
+        gv.copy_(g)
+    fb.extra[0] = loss
+    scale = dp.allreduce_bucket_(fb.bucket, fb.numel + 1)
+    assert scale == 1.0 / world
+    if rank == 0:
+        torch.save({"bucket": fb.bucket.clone() * scale, "numel": fb.numel}, os.path.join(out_dir, "dp.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bucket_allreduce_equals_single_process(tmp_path):
+    port = _free_port()
+    mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    got = torch.load(tmp_path / "dp.pt", weights_only=True)
+    torch.manual_seed(0)
+    disc = osn.Discriminator(input_hw=HW).apply(osn.weights_init)
+    real, fake, _ = synthetic.simnn_inputs(GLOBAL_B, HW, seed=42)
+    loss, grads = _local_grads(disc, real, fake)
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    n = got["numel"]
+    assert n == flat.numel()
+    torch.testing.assert_close(got["bucket"][:n], flat, rtol=1e-5, atol=1e-7)
+    assert abs(got["bucket"][n].item() - loss.item()) < 1e-6
+
+
+def test_flat_buffers_views_alias_parameters_and_grads():
+    torch.manual_seed(1)
+    disc = osn.Discriminator(input_hw=HW)
+    before = [p.detach().clone() for p in disc.parameters()]
+    fb = FlatBuffers(list(disc.parameters()), extra=4)
+    assert fb.numel == sum(p.numel() for p in disc.parameters()) and fb.bucket.numel() == fb.numel + 4
+    off = 0
+    for p, b0 in zip(disc.parameters(), before):
+        assert torch.equal(p.detach(), b0)
+        assert p.data_ptr() == fb.flat.data_ptr() + 4 * off and p.grad.data_ptr() == fb.grad.data_ptr() + 4 * off
+        off += p.numel()
+    with pytest.raises(Exception):
+        fb.adam(1e-3, (0.9, 0.999), 1e-8)      # the optimizer step is HIP-only: no CPU fallback
+
+
+def test_shard_bounds():
+    assert [dp.shard_bounds(2048, 8, r) for r in (0, 7)] == [(0, 256), (1792, 2048)]
+    with pytest.raises(ValueError):
+        dp.shard_bounds(10, 4, 0)
