@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--seq", type=int, default=50, help="piano-roll length T (mmgan)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--no-overlap", action="store_true", help="single stream (no concurrent branches)")
     return ap.parse_args()
 
 
@@ -82,12 +84,17 @@ def build_simnn(args, rank, dev):
     torch.manual_seed(0)   # identical replicas on every rank
     gen = SIMNN.Generator().apply(SIMNN.weights_init).to(dev)
     disc = SIMNN.Discriminator(input_hw=hw).apply(SIMNN.weights_init).to(dev)
-    tr = SimnnTrainer(gen, disc, compute_dtype=args.dtype, elide_dead_backward=(args.mode == "elided"))
+    tr = SimnnTrainer(gen, disc, compute_dtype=args.dtype, elide_dead_backward=(args.mode == "elided"),
+                      overlap=not args.no_overlap)
     real, fake, noise = synthetic.simnn_inputs(args.batch, hw, seed=1234 + rank, device=dev)
 
-    def step():
+    def eager():
         return tr.step(real, noise, fake)
-    return tr, step
+    step = eager
+    if not args.no_graph and tr.world == 1:
+        tr.capture(real, noise, fake)      # the whole iteration (all stream branches) as one hipGraph
+        step = tr.replay
+    return tr, step, eager
 
 
 def build_mmgan(args, rank, dev):
@@ -103,7 +110,7 @@ def build_mmgan(args, rank, dev):
     def step():
         return tr.step(d["piano_roll"], d["durations"], d["beats"], d["noise1"], d["noise2"], d["fake_a"],
                        d["fake_b"], g1_in_a=d["g1_in_a"], g1_in_b=d["g1_in_b"])
-    return tr, step
+    return tr, step, step
 
 
 def host_cores():
@@ -169,7 +176,7 @@ def main():
     import torch.distributed as dist
     from gan_des_midi_music_gen_amd import ops
 
-    tr, step = (build_simnn if args.workload == "simnn" else build_mmgan)(args, rank, dev)
+    tr, step, eager_step = (build_simnn if args.workload == "simnn" else build_mmgan)(args, rank, dev)
 
     def barrier():
         if world > 1:
@@ -193,9 +200,9 @@ def main():
     roofline = None
     if not args.no_roofline:
         dk = dominant_kernel(args.workload, args.dtype, (128, args.width), args.seq)
-        ops.time_entry_point(dk["name"])
+        ops.time_entry_point(dk["name"])     # event pairs need eager launches (a replayed graph has no host calls)
         for _ in range(args.steps):
-            step()
+            eager_step()
         torch.cuda.synchronize()
         avg_ms, launches = ops.timed_durations_ms()
         ops.time_entry_point(None)
@@ -231,7 +238,9 @@ def main():
                              if args.workload == "simnn" else
                              "MMGAN (G + beat-G + D) iteration, MAESTRO-shaped synthetic (2,128,%d) rolls" % args.seq),
                 "per_gpu_batch": args.batch, "global_batch": args.batch * world, "mode": args.mode,
-                "parallelism": f"dp{world}", "iteration": "1 G fwd, 3 D fwd, 2 D bwd, Adam(D)" if
+                "parallelism": f"dp{world}", "launch": "eager" if (args.no_graph or world > 1 or
+                                                                    args.workload != "simnn") else "hipGraph replay",
+                "iteration": "1 G fwd, 3 D fwd, 2 D bwd, Adam(D)" if
                 args.workload == "simnn" else "2x(G1,G2) fwd, 3 D fwd, 2 D bwd, Adam(D)",
             },
             "final_losses": {"disc": round(losses[0], 6), "gen": round(losses[1], 6)},

@@ -20,6 +20,7 @@ SIGNATURES = {
     "gdm_gemm": (_I, [_P, _I, _L, _L, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _I, _F, _I, _I, _P, _Z, _P]),
     "gdm_bce_with_logits": (_I, [_P, _F, _I, _F, _P, _P, _I, _I, _P]),
     "gdm_adam_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P]),
+    "gdm_adam_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P]),
     "gdm_bn_workspace_bytes": (_Z, [_I, _I]),
     "gdm_bn_act_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P, _I, _P, _P, _I, _P, _Z, _P]),
     "gdm_bn_act_bwd": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
@@ -32,7 +33,8 @@ SIGNATURES = {
     "gdm_simnn_conv2_pack": (_I, [_P, _I, _P, _P]),
     "gdm_simnn_conv2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "gdm_simnn_conv2_bwd_fused_workspace_bytes": (_Z, [_I, _I, _I]),
-    "gdm_simnn_conv2_bwd_fused": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _P, _Z, _P]),
+    "gdm_simnn_conv2_bwd_fused": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _P, _Z, _P]),
+    "gdm_simnn_conv2_bwd_fused_finish": (_I, [_I, _I, _I, _P, _P, _P, _Z, _P]),
     "gdm_simnn_conv2_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P]),
     "gdm_simnn_conv2_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I]),
     "gdm_simnn_conv2_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),

@@ -70,6 +70,56 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Device-resident optimizer state for graph replay: hyper[0] = step (int bits), [1] lr, [2] beta1, [3] beta2, [4] eps,
+// [5] grad_scale, [6] step_size (derived), [7] sqrt(bias_correction2) (derived).  adam_prep advances the step and
+// derives the two bias-correction terms in double, like torch does on the host.
+__global__ void adam_prep_kernel(float* __restrict__ hyper) {
+  int step = __float_as_int(hyper[0]) + 1;
+  hyper[0] = __int_as_float(step);
+  const double b1 = (double)hyper[2], b2 = (double)hyper[3];
+  const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+  hyper[6] = (float)((double)hyper[1] / bc1);
+  hyper[7] = (float)sqrt(bc2);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                       const float* __restrict__ hyper) {
+  const float w1 = 1.0f - hyper[2], beta2 = hyper[3], omb2 = 1.0f - hyper[3], eps = hyper[4], gscale = hyper[5];
+  const float step_size = hyper[6], bc2_sqrt = hyper[7];
+  const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+    if (VEC && i + 3 < n) {
+      f32x4 pp = *(const f32x4*)(p + i), gg = *(const f32x4*)(g + i), mm = *(const f32x4*)(m + i),
+            vv = *(const f32x4*)(v + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gj = gg[j] * gscale;
+        const float mj = (w1 < 0.5f) ? mm[j] + w1 * (gj - mm[j]) : gj - (gj - mm[j]) * (1.f - w1);
+        const float vj = vv[j] * beta2 + omb2 * gj * gj;
+        const float denom = sqrtf(vj) / bc2_sqrt + eps;
+        pp[j] = pp[j] - step_size * (mj / denom);
+        mm[j] = mj;
+        vv[j] = vj;
+      }
+      *(f32x4*)(p + i) = pp;
+      *(f32x4*)(m + i) = mm;
+      *(f32x4*)(v + i) = vv;
+    } else {
+      for (int64_t k = i; k < n && k < i + 4; ++k) {
+        const float gj = g[k] * gscale;
+        const float mj = (w1 < 0.5f) ? m[k] + w1 * (gj - m[k]) : gj - (gj - m[k]) * (1.f - w1);
+        const float vj = v[k] * beta2 + omb2 * gj * gj;
+        const float denom = sqrtf(vj) / bc2_sqrt + eps;
+        p[k] = p[k] - step_size * (mj / denom);
+        m[k] = mj;
+        v[k] = vj;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------- batch norm fwd
 // Stage 1: per (row-chunk, column) Welford triple (count, mean, M2); lanes = 64 consecutive columns, the 4 waves
 // of a workgroup interleave rows and are merged in wave order (Chan's formula).
@@ -316,6 +366,20 @@ extern "C" int gdm_adam_step(float* p, const float* g, float* m, float* v, int64
     hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                        1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2_sqrt, eps, grad_scale);
   GDM_LAUNCH_OK("gdm_adam_step");
+  return GDM_OK;
+}
+
+extern "C" int gdm_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* hyper, void* stream) {
+  GDM_REQUIRE(p && g && m && v && hyper && n > 0, "gdm_adam_step_dev: bad arguments");
+  const bool aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, s, hyper);
+  if (aligned) hipLaunchKernelGGL(adam_dev_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, hyper);
+  else hipLaunchKernelGGL(adam_dev_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, hyper);
+  GDM_LAUNCH_OK("gdm_adam_step_dev");
   return GDM_OK;
 }
 

@@ -733,9 +733,15 @@ inline int conv1_slabs(int64_t total) {
 }
 inline int conv2w_blocks(int n_units) { return n_units < 512 ? n_units : 512; }
 
+// Raise a kernel's dynamic-LDS limit once per process (not a stream operation: kept out of graph capture by doing it
+// on the first, un-captured launch only; the size per kernel instantiation never changes).
 template <typename K>
 inline void allow_lds(K kernel, size_t bytes) {
-  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  static bool done = false;    // one static per template instantiation = per kernel
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    done = true;
+  }
 }
 
 }  // namespace
@@ -857,9 +863,9 @@ extern "C" size_t gdm_simnn_conv2_bwd_fused_workspace_bytes(int B, int H1, int W
 
 extern "C" int gdm_simnn_conv2_bwd_fused(const void* dp2, const uint8_t* code2, const void* pack, int B, int H1, int W1,
                                          const uint64_t* code1, const float* x0, const float* x1, int bsplit, int H,
-                                         int W, void* dp1_or_null, float* dw1, float* db1, int dtype, void* workspace,
-                                         size_t workspace_bytes, void* stream) {
-  GDM_REQUIRE(dp2 && code2 && pack && code1 && x0 && dw1 && db1, "gdm_simnn_conv2_bwd_fused: null pointer");
+                                         int W, void* dp1_or_null, int dtype, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  GDM_REQUIRE(dp2 && code2 && pack && code1 && x0, "gdm_simnn_conv2_bwd_fused: null pointer");
   GDM_REQUIRE(B > 0 && B <= 65535 && gdm_dtype_ok(dtype), "gdm_simnn_conv2_bwd_fused: bad arguments");
   GDM_REQUIRE(H1 == (H + 1) / 2 && W1 == (W + 1) / 2 && H1 >= 2 && W1 >= 2,
               "gdm_simnn_conv2_bwd_fused: (H1,W1)=(%d,%d) does not belong to a %dx%d input", H1, W1, H, W);
@@ -870,19 +876,30 @@ extern "C" int gdm_simnn_conv2_bwd_fused(const void* dp2, const uint8_t* code2, 
     return GDM_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int nblocks = B * ((H1 + ROWS - 1) / ROWS) * ((W1 + BD_COLS - 1) / BD_COLS);
   float* slabs = (float*)workspace;
   int rc = dtype == GDM_BF16
                ? launch_bwd_data<__bf16, true>(dp2, code2, pack, B, H1, W1, dp1_or_null, code1, x0, x1, bsplit, H, W,
                                                slabs, s)
                : launch_bwd_data<float, true>(dp2, code2, pack, B, H1, W1, dp1_or_null, code1, x0, x1, bsplit, H, W,
                                               slabs, s);
-  if (rc != GDM_OK) return rc;
+  return rc;
+}
+
+extern "C" int gdm_simnn_conv2_bwd_fused_finish(int B, int H1, int W1, float* dw1, float* db1, void* workspace,
+                                                size_t workspace_bytes, void* stream) {
+  GDM_REQUIRE(dw1 && db1 && B > 0 && H1 >= 2 && W1 >= 2, "gdm_simnn_conv2_bwd_fused_finish: bad arguments");
+  if (!workspace || workspace_bytes < gdm_simnn_conv2_bwd_fused_workspace_bytes(B, H1, W1)) {
+    gdm_set_error("gdm_simnn_conv2_bwd_fused_finish: workspace too small");
+    return GDM_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int nblocks = B * ((H1 + ROWS - 1) / ROWS) * ((W1 + BD_COLS - 1) / BD_COLS);
+  float* slabs = (float*)workspace;
   float* scratch = slabs + (size_t)nblocks * 80;
   float* sums = scratch + 64 * 80;
   launch_slab_sum(slabs, nblocks, 80, scratch, sums, s);
   hipLaunchKernelGGL(conv1_bwd_weight_final, dim3(1), dim3(128), 0, s, (const float*)sums, dw1, db1, 0);
-  GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_fused");
+  GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_fused_finish");
   return GDM_OK;
 }
 

@@ -43,11 +43,17 @@ def _f32c(t):
 # ======================================================================================================================
 # Model 1 discriminator (GAN_DES/SIMNN.py:115-142)
 # ======================================================================================================================
-def simnn_disc_prepare(w2, wf1, dt):
+def simnn_disc_prepare(w2, wf1, dt, out=None):
     """Per-weight-version operands: conv2's packed MFMA images and fc1's weight permuted to the channels-last flatten
-    order of the feature map (and cast to the activation dtype).  (128, 32*P) -> (128, P*32)."""
-    pack = ops.simnn_conv2_pack(w2, dt)
+    order of the feature map (and cast to the activation dtype).  (128, 32*P) -> (128, P*32).
+    ``out`` = a previous result to refresh in place (persistent buffers: required under graph replay)."""
     n, k = wf1.shape
+    if out is not None:
+        pack, wf1p = out
+        ops.simnn_conv2_pack(w2, dt, out=pack)
+        ops.permute_pc(wf1, n, 32, k // 32, out=wf1p)
+        return pack, wf1p
+    pack = ops.simnn_conv2_pack(w2, dt)
     wf1p = ops.permute_pc(wf1, n, 32, k // 32, out_dtype=dt).view(n, k)
     return pack, wf1p
 

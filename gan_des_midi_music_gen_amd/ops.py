@@ -141,6 +141,21 @@ def adam_step(p, g, m, v, step, lr, beta1, beta2, eps, grad_scale=1.0):
                                     float(beta2), float(eps), float(grad_scale), _stream())
 
 
+def adam_hyper(device, lr, beta1, beta2, eps, grad_scale=1.0, step=0):
+    """8-float device record for adam_step_dev: {step (int bits), lr, beta1, beta2, eps, grad_scale, -, -}."""
+    h = torch.zeros(8, dtype=torch.float32)
+    h[1], h[2], h[3], h[4], h[5] = lr, beta1, beta2, eps, grad_scale
+    h.view(torch.int32)[0] = int(step)
+    return h.to(device)
+
+
+def adam_step_dev(p, g, m, v, hyper):
+    """Adam step whose step counter / hyper-parameters live in `hyper` on the device (graph-replayable)."""
+    _need_gpu(p, g, m, v, hyper)
+    assert hyper.numel() == 8 and hyper.dtype == torch.float32
+    _call("gdm_adam_step_dev", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _stream())
+
+
 def bn_act_fwd(y, gamma, beta, running_mean, running_var, nbt, *, act, out_dtype=F32, training=True, momentum=0.1,
                eps=1e-5):
     """y (rows, C) fp32 -> (out, save_mean, save_invstd)."""
@@ -231,12 +246,14 @@ def simnn_conv1_fwd(x, w, bias, dt, out=None):
     return p1, code1
 
 
-def simnn_conv2_pack(w, dt):
+def simnn_conv2_pack(w, dt, out=None):
     """Packed MFMA operand images (forward + flipped backward) of conv2's weight; rebuild when w changes."""
-    _need_gpu(w)
+    _need_gpu(w, out)
     assert w.shape == (32, 16, 3, 3) and w.dtype == torch.float32 and w.is_contiguous()
     lib = _lib.load()
-    pack = torch.empty(lib.gdm_simnn_conv2_pack_bytes(dt), dtype=torch.uint8, device=w.device)
+    nbytes = lib.gdm_simnn_conv2_pack_bytes(dt)
+    pack = out if out is not None else torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    assert pack.numel() == nbytes and pack.dtype == torch.uint8
     _call("gdm_simnn_conv2_pack", _p(w), dt, _p(pack), _stream())
     return pack
 
@@ -288,7 +305,8 @@ def simnn_conv2_bwd_fused(dp2, code2, pack, code1, x0, x1=None, out=None, want_d
     nb = lib.gdm_simnn_conv2_bwd_fused_workspace_bytes(b, h1, w1)
     ws = workspace(nb, x0.device)
     _call("gdm_simnn_conv2_bwd_fused", _p(dp2), _p(code2), _p(pack), b, h1, w1, _p(code1), _p(x0), _p(x1), bsplit, h,
-          wd, _p(dp1), _p(dw), _p(db), gdm_dtype(dp2), _p(ws), nb, _stream())
+          wd, _p(dp1), gdm_dtype(dp2), _p(ws), nb, _stream())
+    _call("gdm_simnn_conv2_bwd_fused_finish", b, h1, w1, _p(dw), _p(db), _p(ws), nb, _stream())
     return dw, db, dp1
 
 

@@ -50,11 +50,23 @@ class FlatBuffers:
             self.grad_views.append(g)
             off += n
         self.step_count = 0
+        self._hyper = None
+        self._hyper_host = None
 
     def adam(self, lr, betas, eps, grad_scale=1.0):
+        """One fused Adam launch over the flat buffer.  Step counter and hyper-parameters live in an 8-float device
+        record (so a captured hipGraph replays correctly); the host only rewrites it when lr/scale change."""
+        want = (float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale))
+        if self._hyper is None:
+            self._hyper = ops.adam_hyper(self.flat.device, *want, step=self.step_count)
+            self._hyper_host = want
+        elif want != self._hyper_host:
+            if torch.cuda.is_current_stream_capturing():
+                raise ops.GdmError("optimizer hyper-parameters changed inside a captured step: re-capture the graph")
+            self._hyper[1:6].copy_(torch.tensor(want, dtype=torch.float32), non_blocking=False)
+            self._hyper_host = want
         self.step_count += 1
-        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_count, lr, betas[0], betas[1], eps,
-                      grad_scale)
+        ops.adam_step_dev(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self._hyper)
 
 
 class _TrainerBase:
@@ -82,16 +94,26 @@ class _TrainerBase:
 
 
 class SimnnTrainer(_TrainerBase):
-    """One object per (Generator, Discriminator) pair of model 1; ``step`` = one iteration of SIMNN.py:276-334."""
+    """One object per (Generator, Discriminator) pair of model 1; ``step`` = one iteration of SIMNN.py:276-334.
+
+    overlap=True runs the independent branches of the iteration on side HIP streams (generator forward beside the
+    discriminator step; fc1's weight gradient and conv2's weight gradient beside the data-gradient chain); all
+    branches re-join before the optimizer and before ``step`` returns.  ``capture``/``replay`` record the whole
+    iteration (all branches) into one hipGraph for fixed input buffers.
+    """
 
     def __init__(self, gen, disc, lr=0.00002, betas=(0.5, 0.999), eps=1e-8, compute_dtype=None,
-                 elide_dead_backward=False, process_group=None):
+                 elide_dead_backward=False, process_group=None, overlap=True):
         self.gen, self.disc = gen, disc
         self._init_common([disc.conv1.weight, disc.conv1.bias, disc.conv2.weight, disc.conv2.bias, disc.fc1.weight,
                            disc.fc1.bias, disc.fc2.weight, disc.fc2.bias], lr, betas, eps, compute_dtype,
                           elide_dead_backward, process_group)
         self.last_generated = None
         self._prepared = None      # (packed conv2 images, permuted fc1 weight) for the current weights
+        self.overlap = overlap
+        self._side = None
+        self._graph = None
+        self._scratch_grads = None
 
     def invalidate_weights(self):
         """Call after changing discriminator weights from outside (e.g. load_state_dict)."""
@@ -104,6 +126,43 @@ class SimnnTrainer(_TrainerBase):
                for bn in (g.batch_norm1, g.batch_norm2, g.batch_norm3)]
         return ws, bns
 
+    def _streams(self, dev):
+        if self._side is None:
+            self._side = [torch.cuda.Stream(dev) for _ in range(3)]
+        return self._side
+
+    def _d_backward(self, saved, dh, pack, wf1p, outs, x_pair, keep):
+        """Discriminator backward below the head: three independent branches after dh1 / dp2 are known."""
+        dt = self.dt
+        x, p1, code1, flat, code2 = saved[:5]
+        b = p1.shape[0]
+        n, k = wf1p.shape
+        main = torch.cuda.current_stream()
+        side = self._streams(p1.device) if self.overlap else None
+        # branch A: fc1 weight gradient (GEMM + permute back to the parameter's flatten order)
+        if side:
+            side[1].wait_stream(main)
+        with torch.cuda.stream(side[1] if side else main):
+            dwf1p = ops.gemm(dh.t(), flat, compute=dt)
+            ops.permute_pc(dwf1p, n, k // 32, 32, out=outs[4])
+            keep.append(dwf1p)
+        # main: fc1 data gradient = pooled gradient of the conv trunk
+        dflat = ops.gemm(dh, wf1p, compute=dt, out_dtype=dt)
+        h1s, w1s = p1.shape[1], p1.shape[2]
+        dp2 = dflat.view(b, h1s // 2, w1s // 2, 32)
+        keep.append(dflat)
+        # branch B: conv2 weight gradient
+        if side:
+            side[2].wait_stream(main)
+        with torch.cuda.stream(side[2] if side else main):
+            ops.simnn_conv2_bwd_weight(dp2, code2, p1, out=(outs[2], outs[3]))
+        # main: conv2 data gradient with conv1's weight gradient fused in
+        x0, x1 = x_pair if x_pair is not None else (x, None)
+        ops.simnn_conv2_bwd_fused(dp2, code2, pack, code1, x0, x1, out=(outs[0], outs[1]))
+        if side:
+            main.wait_stream(side[1])
+            main.wait_stream(side[2])
+
     @torch.no_grad()
     def step(self, real, noise, fake):
         """real (B,H,W) fp32 on the device; noise (B,noise_dim,1,1); fake: (B,H,W) tensor, or a callable
@@ -111,13 +170,23 @@ class SimnnTrainer(_TrainerBase):
         Returns (disc_loss, gen_loss) as 1-element device tensors (this rank's batch means)."""
         dt = self.dt
         w1, b1, w2, b2, wf1, bf1, wf2, bf2 = self.d.views
+        gv = self.d.grad_views
         real = Fn._f32c(real)
         b, h, w = real.shape
-        # --- generator forward (SIMNN.py:293-296); its output only feeds the (external) bridge
+        main = torch.cuda.current_stream()
+        side = self._streams(real.device) if self.overlap else None
+        keep = []
+        # --- generator forward (SIMNN.py:293-296); its output only feeds the (external) bridge -> own stream
         ws, bns = self._gen_state()
-        generated, _ = Fn.simnn_gen_forward(noise, ws, bns, self.gen.training, dt)
+        if side:
+            side[0].wait_stream(main)
+        with torch.cuda.stream(side[0] if side else main):
+            generated, gsaved = Fn.simnn_gen_forward(noise, ws, bns, self.gen.training, dt)
+            keep.append(gsaved)
         self.last_generated = generated
         if callable(fake):
+            if side:
+                main.wait_stream(side[0])
             fake = fake(generated)
         fake = Fn._f32c(fake.to(real.device))
         assert fake.shape == real.shape, (fake.shape, real.shape)
@@ -132,21 +201,51 @@ class SimnnTrainer(_TrainerBase):
         ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
         ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
         hid, saved = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1, code1))
-        gv = self.d.grad_views
-        # fc2 + sigmoid + both BCE terms (labels 0.9 / 0.1, SIMNN.py:284-311) + head backward: one launch
+        # fc2 + sigmoid + both BCE terms (labels 0.9 / 0.1, SIMNN.py:284-311) + head backward: one launch pair
         _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 0.9, 0.1, loss_out=self.loss_d, grad_out=(gv[6], gv[7], gv[5]))
-        Fn.simnn_disc_backward_from_dh1(saved, dh, pack, wf1p, dt, out=gv, x_pair=(real, fake))
+        self._d_backward(saved, dh, pack, wf1p, gv, (real, fake), keep)
         self._reduce_and_step()
         # weights changed: rebuild the packed conv2 images and the permuted fc1 operand once, use them for the G-step
         # forward below AND for the next iteration's D-step forward
-        self._prepared = pack, wf1p = Fn.simnn_disc_prepare(w2, wf1, dt)
+        # (refreshed in place: they are cross-iteration state, so their storage must be stable under graph replay)
+        Fn.simnn_disc_prepare(w2, wf1, dt, out=self._prepared)
         # --- "generator" step (SIMNN.py:322-331): D forward on fake with the updated weights, label 1.0
-        hid, saved = Fn.simnn_disc_features(fake, w1, b1, pack, b2, wf1p, bf1, dt)
-        _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 1.0, 1.0, loss_out=self.loss_g, want_grad=not self.elide)
+        hid_g, saved_g = Fn.simnn_disc_features(fake, w1, b1, pack, b2, wf1p, bf1, dt)
+        _prob, dh_g, _ = ops.simnn_head(hid_g, wf2, bf2, b, 1.0, 1.0, loss_out=self.loss_g, want_grad=not self.elide)
         if not self.elide:
-            # dead values: gen_loss.backward() only fills D's .grad, which the next zero_grad() wipes (SIMNN.py:330, 282)
-            Fn.simnn_disc_backward_from_dh1(saved, dh, pack, wf1p, dt)
+            # dead values: gen_loss.backward() only fills D's .grad, which the next zero_grad() wipes (SIMNN.py:330,
+            # 282); they are computed (faithful mode) into a scratch set of gradient buffers
+            if self._scratch_grads is None:
+                self._scratch_grads = [torch.empty_like(g) for g in gv]
+            self._d_backward(saved_g, dh_g, pack, wf1p, self._scratch_grads, None, keep)
+        if side:
+            main.wait_stream(side[0])
         # gen_opt.step(): every generator .grad is None -> no-op
+        self.iterations += 1
+        del keep
+        return self.loss_d, self.loss_g
+
+    # ---- hipGraph capture of the whole iteration for fixed input buffers -------------------------------------------
+    def capture(self, real, noise, fake):
+        """Record one iteration on (real, noise, fake) -- tensors whose storage is re-used for every replay -- into a
+        hipGraph.  Not available with a callable bridge or with more than one rank."""
+        if callable(fake) or self.world > 1:
+            raise ops.GdmError("graph capture needs tensor inputs and a single rank")
+        self._static = (Fn._f32c(real), noise, Fn._f32c(fake))
+        warm = torch.cuda.Stream(real.device)
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
+            for _ in range(2):
+                self.step(*self._static)
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self.step(*self._static)
+        return self._graph
+
+    def replay(self):
+        self._graph.replay()
         self.iterations += 1
         return self.loss_d, self.loss_g
 

@@ -62,6 +62,11 @@ int gdm_bce_with_logits(const float* x, float target, int n, float grad_scale, f
 int gdm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int step, float lr, float beta1,
                   float beta2, float eps, float grad_scale, void* stream);
 
+/* the same update with the step counter and hyper-parameters resident on the device, so that a captured hipGraph can
+ * be replayed: hyper = 8 floats {step (int32 bits), lr, beta1, beta2, eps, grad_scale, -, -}; every call increments
+ * the step and recomputes the bias corrections on the device (in double), then updates the flat range.             */
+int gdm_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* hyper, void* stream);
+
 /* ---- batch norm, training mode, rows x channels matrices (aten::native_batch_norm + activation) ----------------
  * y: (rows, channels) fp32 pre-norm values (row-major).  Computes per-channel batch mean / biased variance with a
  * fixed-order Welford merge, updates running_mean/var (momentum, unbiased var) and num_batches_tracked, and writes
@@ -115,12 +120,15 @@ int gdm_simnn_conv2_bwd_data(const void* dp2, const uint8_t* code2, const void* 
 /* the same data gradient with conv1's weight gradient fused into its epilogue: dp1 is routed through code1 and
  * contracted with the input windows while it is still in registers, so it never goes to HBM (dp1_or_null = NULL).
  * Samples [0,bsplit) read their input from x0, samples [bsplit,B) from x1 (the 2B batch [real ; fake]).
- * Writes dw1 (16,1,2,2), db1 (16).  workspace >= gdm_simnn_conv2_bwd_fused_workspace_bytes(B,H1,W1).              */
+ * The kernel leaves one slab of 80 partial sums per workgroup in `workspace`
+ * (>= gdm_simnn_conv2_bwd_fused_workspace_bytes(B,H1,W1)); gdm_simnn_conv2_bwd_fused_finish (same B,H1,W1,workspace)
+ * adds the slabs in fixed order into dw1 (16,1,2,2), db1 (16).                                                      */
 size_t gdm_simnn_conv2_bwd_fused_workspace_bytes(int B, int H1, int W1);
 int gdm_simnn_conv2_bwd_fused(const void* dp2, const uint8_t* code2, const void* pack, int B, int H1, int W1,
                               const uint64_t* code1, const float* x0, const float* x1, int bsplit, int H, int W,
-                              void* dp1_or_null, float* dw1, float* db1, int dtype, void* workspace,
-                              size_t workspace_bytes, void* stream);
+                              void* dp1_or_null, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+int gdm_simnn_conv2_bwd_fused_finish(int B, int H1, int W1, float* dw1, float* db1, void* workspace,
+                                     size_t workspace_bytes, void* stream);
 /* dW2 (32,16,3,3), db2 (32): deterministic slab reduction; workspace >= gdm_simnn_conv2_bwd_weight_workspace_bytes */
 size_t gdm_simnn_conv2_bwd_weight_workspace_bytes(int B, int H1, int W1);
 int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2, const void* p1, int B, int H1, int W1,

@@ -224,6 +224,30 @@ def test_full_size_properties(mode):
     assert all(torch.equal(u, v) for u, v in zip(g_all, g_again)), "backward must be deterministic"
 
 
+def test_stream_overlap_and_graph_replay_are_bit_identical_to_single_stream():
+    hw, b = (128, 216), 4
+    outs = []
+    for mode in ("single", "overlap", "graph"):
+        gen, disc = _build(7, True)
+        gen.to(DEV), disc.to(DEV)
+        tr = SimnnTrainer(gen, disc, compute_dtype="bf16", overlap=(mode != "single"))
+        real, fake, noise = synthetic.simnn_inputs(b, hw, seed=55, device=DEV)
+        if mode == "graph":
+            tr.capture(real, noise, fake)           # runs 2 warm-up iterations itself
+            for _ in range(3):
+                dl, gl = tr.replay()
+        else:
+            for _ in range(5):
+                dl, gl = tr.step(real, noise, fake)
+        torch.cuda.synchronize()
+        outs.append((dl.item(), gl.item(), disc.fc1.weight.detach().clone(), disc.conv1.weight.detach().clone(),
+                     gen.batch_norm2.running_var.clone(), int(gen.batch_norm1.num_batches_tracked.item())))
+    for mode, o in zip(("overlap", "graph"), outs[1:]):
+        assert o[0] == outs[0][0] and o[1] == outs[0][1], (mode, o[:2], outs[0][:2])
+        assert torch.equal(o[2], outs[0][2]) and torch.equal(o[3], outs[0][3]) and torch.equal(o[4], outs[0][4]), mode
+        assert o[5] == outs[0][5] == 5, mode
+
+
 def test_train_entry_point_runs_and_checkpoints(tmp_path):
     gen, disc, g_losses, d_losses = SIMNN.train(None, batch_size=4, max_steps=7, model_path=str(tmp_path), seed=0,
                                                 log=lambda *_: None)
