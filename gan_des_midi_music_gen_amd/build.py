@@ -12,6 +12,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libgdm_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("GDM_HIPCC_FLAGS", "").split()     # experiment switches (-D...), empty for the shipped build
 
 
 def _hipcc():

@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int COLS = 128;  // conv-output columns handled per workgroup (column super-tile)
+constexpr int COLS = 64;   // conv-output columns handled per workgroup (column super-tile)
 
 template <typename T> struct Px;  // LDS pixel-record strides (elements) for 16- and 32-channel records
 template <> struct Px<float> { static constexpr int S16 = 17, S32 = 33; };
@@ -244,25 +244,41 @@ __device__ __forceinline__ void copy_to_lds(T* __restrict__ dst, const T* __rest
   for (int i = threadIdx.x; i < chunks; i += 256) ((f32x4*)dst)[i] = ((const f32x4*)src)[i];
 }
 
-// p1 halo band (rows r_first .. r_first+NR-1, cols c_first .. c_first+WP-1) -> LDS [row][col][S16], zero outside
+// p1 halo band (rows r_first .. r_first+NR-1, cols c_first .. c_first+WP-1) -> LDS [row][col][S16], zero outside.
+// Two phases so that every global load of the tile is in flight before the first LDS store.
+template <typename T, int NR> struct P1Stage {
+  static constexpr int PIECES = (sizeof(T) == 2) ? 2 : 4;          // 16-byte pieces per pixel record
+  static constexpr int ITERS = (NR * C2<T>::WP * PIECES + 255) / 256;
+  f32x4 v[ITERS];
+};
+
 template <typename T, int NR>
-__device__ __forceinline__ void stage_p1_band(const T* __restrict__ p1b, int H1, int W1, int r_first, int c_first,
-                                              T* __restrict__ in_s) {
-  constexpr int S16 = C2<T>::S16, WP = C2<T>::WP;
-  constexpr int PIECES = (sizeof(T) == 2) ? 2 : 4, EPP = 16 / PIECES;
-  for (int i = threadIdx.x; i < NR * WP * PIECES; i += 256) {
+__device__ __forceinline__ void p1_band_load(P1Stage<T, NR>& st, const T* __restrict__ p1b, int H1, int W1,
+                                             int r_first, int c_first) {
+  constexpr int WP = C2<T>::WP, PIECES = P1Stage<T, NR>::PIECES, EPP = 16 / PIECES;
+#pragma unroll
+  for (int k = 0; k < P1Stage<T, NR>::ITERS; ++k) {
+    const int i = threadIdx.x + 256 * k;
     const int piece = i % PIECES, pix = i / PIECES;
     const int cl = pix % WP, rl = pix / WP;
     const int r = r_first + rl, c = c_first + cl;
-    T* dst = in_s + (rl * WP + cl) * S16 + piece * EPP;
-    if (r >= 0 && r < H1 && c >= 0 && c < W1) {
-      const T* s = p1b + ((int64_t)r * W1 + c) * 16 + piece * EPP;
-      if constexpr (sizeof(T) == 2) *(bf16x8*)dst = *(const bf16x8*)s;
-      else { const f32x4 v = *(const f32x4*)s; dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
-    } else {
+    st.v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (i < NR * WP * PIECES && r >= 0 && r < H1 && c >= 0 && c < W1)
+      st.v[k] = *(const f32x4*)(p1b + ((int64_t)r * W1 + c) * 16 + piece * EPP);
+  }
+}
+
+template <typename T, int NR>
+__device__ __forceinline__ void p1_band_store(const P1Stage<T, NR>& st, T* __restrict__ in_s) {
+  constexpr int S16 = C2<T>::S16, WP = C2<T>::WP, PIECES = P1Stage<T, NR>::PIECES, EPP = 16 / PIECES;
 #pragma unroll
-      for (int e = 0; e < EPP; ++e) dst[e] = from_f32<T>(0.f);
-    }
+  for (int k = 0; k < P1Stage<T, NR>::ITERS; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i >= NR * WP * PIECES) continue;
+    const int piece = i % PIECES, pix = i / PIECES;
+    T* dst = in_s + pix * S16 + piece * EPP;
+    if constexpr (sizeof(T) == 2) *(f32x4*)dst = st.v[k];
+    else { dst[0] = st.v[k][0]; dst[1] = st.v[k][1]; dst[2] = st.v[k][2]; dst[3] = st.v[k][3]; }
   }
 }
 
@@ -359,18 +375,21 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
   T* w_s = in_s + C2<T>::IN_ELEMS;
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
   const int c0 = blockIdx.x * COLS, rq = blockIdx.y, b = blockIdx.z;
+  const int rp = wv >> 1, half = wv & 1;            // wave -> (pooled row of the tile, 32-column half)
+  P1Stage<T, ROWS + 2> st;
+  p1_band_load(st, p1 + (int64_t)b * H1 * W1 * 16, H1, W1, ROWS * rq - 1, c0 - 1);
   copy_to_lds(w_s, wf, C2<T>::WF_ELEMS);
-  stage_p1_band<T, ROWS + 2>(p1 + (int64_t)b * H1 * W1 * 16, H1, W1, ROWS * rq - 1, c0 - 1, in_s);
+  p1_band_store(st, in_s);
   __syncthreads();
 
-  f32x4 acc[2][ROWS][2];
+  f32x4 acc[2][2][2];                               // [m-tile][row of the pair][column tile]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int d = 0; d < ROWS; ++d)
+    for (int d = 0; d < 2; ++d)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][d][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int colb = 32 * wv + lr;
+  const int colb = 32 * half + lr;
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
     for (int ks = 0; ks < 5; ++ks) {
@@ -381,10 +400,10 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8*)&w_s[(16 * i + lr) * KP + 32 * ks + 8 * lg];
 #pragma unroll
-      for (int d = 0; d < ROWS; ++d)
+      for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const bf16x8 bb = *(const bf16x8*)&in_s[((d + kh) * WP + colb + 16 * j + kw) * S16 + 8 * (lg & 1)];
+          const bf16x8 bb = *(const bf16x8*)&in_s[((2 * rp + d + kh) * WP + colb + 16 * j + kw) * S16 + 8 * (lg & 1)];
 #pragma unroll
           for (int i = 0; i < 2; ++i) acc[i][d][j] = mfma16(a[i], bb, acc[i][d][j]);
         }
@@ -398,10 +417,10 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
 #pragma unroll
       for (int i = 0; i < 2; ++i) a[i] = w_s[(16 * i + lr) * KP + 4 * ks + lg];
 #pragma unroll
-      for (int d = 0; d < ROWS; ++d)
+      for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const float bb = in_s[((d + kh) * WP + colb + 16 * j + kw) * S16 + ci];
+          const float bb = in_s[((2 * rp + d + kh) * WP + colb + 16 * j + kw) * S16 + ci];
 #pragma unroll
           for (int i = 0; i < 2; ++i) acc[i][d][j] = mfma16(a[i], bb, acc[i][d][j]);
         }
@@ -410,41 +429,39 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
   // ---- epilogue on the accumulator tile: bias, ReLU, 2x2 max-pool + code; C layout: col (lr) = pixel,
   //      row (4*lg + r) = channel within m-tile i  ->  an even lane owns 4 consecutive channels of one pooled pixel
 #pragma unroll
-  for (int pr = 0; pr < ROWS / 2; ++pr)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) {
+      float best[4];
+      uint32_t codes = 0;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float best[4];
-        uint32_t codes = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float bo = bias[16 * i + 4 * lg + r];
-          float v0 = acc[i][2 * pr][j][r] + bo, v1 = acc[i][2 * pr + 1][j][r] + bo;
-          v0 = v0 > 0.f ? v0 : 0.f;
-          v1 = v1 > 0.f ? v1 : 0.f;
-          const float u0 = __shfl_xor(v0, 1, 64), u1 = __shfl_xor(v1, 1, 64);
-          float bv = v0; uint32_t bi = 0;
-          if (u0 > bv) { bv = u0; bi = 1; }
-          if (v1 > bv) { bv = v1; bi = 2; }
-          if (u1 > bv) { bv = u1; bi = 3; }
-          best[r] = bv;
-          codes |= (bv > 0.f ? bi : 4u) << (8 * r);
-        }
-        const int ph = (ROWS / 2) * rq + pr, pw = (c0 + colb + 16 * j) >> 1;
-        if ((lr & 1) == 0 && ph < H2 && pw < W2) {
-          const int64_t gi = ((((int64_t)b * H2 + ph) * W2 + pw) * 32) + 16 * i + 4 * lg;
-          if constexpr (sizeof(T) == 2) {
-            bf16x4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = (__bf16)best[r];
-            *(bf16x4*)(p2 + gi) = h;
-          } else {
-            *(f32x4*)(p2 + gi) = (f32x4){best[0], best[1], best[2], best[3]};
-          }
-          *(uint32_t*)(code2 + gi) = codes;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const float bo = bias[16 * i + 4 * lg + r];
+        float v0 = acc[i][0][j][r] + bo, v1 = acc[i][1][j][r] + bo;
+        v0 = v0 > 0.f ? v0 : 0.f;
+        v1 = v1 > 0.f ? v1 : 0.f;
+        const float u0 = __shfl_xor(v0, 1, 64), u1 = __shfl_xor(v1, 1, 64);
+        float bv = v0; uint32_t bi = 0;
+        if (u0 > bv) { bv = u0; bi = 1; }
+        if (v1 > bv) { bv = v1; bi = 2; }
+        if (u1 > bv) { bv = u1; bi = 3; }
+        best[r] = bv;
+        codes |= (bv > 0.f ? bi : 4u) << (8 * r);
       }
+      const int ph = (ROWS / 2) * rq + rp, pw = (c0 + colb + 16 * j) >> 1;
+      if ((lr & 1) == 0 && ph < H2 && pw < W2) {
+        const int64_t gi = ((((int64_t)b * H2 + ph) * W2 + pw) * 32) + 16 * i + 4 * lg;
+        if constexpr (sizeof(T) == 2) {
+          bf16x4 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = (__bf16)best[r];
+          *(bf16x4*)(p2 + gi) = h;
+        } else {
+          *(f32x4*)(p2 + gi) = (f32x4){best[0], best[1], best[2], best[3]};
+        }
+        *(uint32_t*)(code2 + gi) = codes;
+      }
+    }
 }
 
 // ---------------------------------------------------------------------------------- conv2 backward (data [+ conv1 dW])
@@ -455,6 +472,10 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
 // window held in LDS:  dW1[c][kh][kw] += live * dp1[c] * x[2ih+dy-1+kh][2iw+dx-1+kw],  db1[c] += live * dp1[c];
 // the workgroup's 80 partial sums go to one slab (summed in fixed order by slab_sum_kernel).
 constexpr int BD_COLS = 64, BD_WP = BD_COLS + 2, BD_XW = 2 * BD_COLS + 4;
+#ifndef GDM_BD_PREFETCH
+#define GDM_BD_PREFETCH 1
+#endif
+constexpr bool BD_PREFETCH = GDM_BD_PREFETCH;
 template <typename T> struct BD {
   static constexpr int DC_ELEMS = (ROWS + 2) * BD_WP * C2<T>::S32;
   static constexpr size_t lds_bytes(bool fuse) {
@@ -462,11 +483,51 @@ template <typename T> struct BD {
   }
 };
 
+// Everything a workgroup has to fetch from HBM for one tile, held in registers between "issue" and "consume":
+// the loads of tile t+1 are issued right after tile t's LDS image is complete, so their latency is covered by tile
+// t's MFMA + epilogue work (software prefetch one tile ahead; the kernel is persistent over tiles).
+template <typename T, bool FUSE> struct BdTileRegs {
+  static constexpr int XIT = (XROWS * BD_XW + 255) / 256;
+  DcStage<T, ROWS + 2, BD_WP, true> dc;
+  float xv[FUSE ? XIT : 1];
+  uint64_t codes[FUSE ? 4 : 1];
+};
+
 template <typename T, bool FUSE>
-__global__ __launch_bounds__(256, 4) void conv2_bwd_data_kernel(const T* __restrict__ dp2,
+__device__ __forceinline__ void bd_issue(BdTileRegs<T, FUSE>& rg, int u, int n_ctiles, int nrq,
+                                         const T* __restrict__ dp2, const uint8_t* __restrict__ code2, int H1, int W1,
+                                         int H2, int W2, const uint64_t* __restrict__ code1,
+                                         const float* __restrict__ x0, const float* __restrict__ x1, int bsplit, int H,
+                                         int W) {
+  constexpr int XW = BD_XW;
+  const int t = threadIdx.x, lr = t & 15, wv = t >> 6;
+  const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq, b = u / (n_ctiles * nrq);
+  const int c0 = ct * BD_COLS;
+  dc2_load(rg.dc, dp2 + (int64_t)b * H2 * W2 * 32, code2 + (int64_t)b * H2 * W2 * 32, H2, W2, ROWS * rq - 1, c0 - 1);
+  if constexpr (FUSE) {
+    const float* xb = (b < bsplit) ? x0 + (int64_t)b * H * W : x1 + (int64_t)(b - bsplit) * H * W;
+#pragma unroll
+    for (int k = 0; k < BdTileRegs<T, FUSE>::XIT; ++k) {
+      const int i = t + 256 * k;
+      const int bc = i % XW, br = i / XW;
+      const int xr = 2 * ROWS * rq - 1 + br, xc = 2 * c0 - 1 + bc;
+      rg.xv[k] = (i < XROWS * XW && xr >= 0 && xr < H && xc >= 0 && xc < W) ? xb[(int64_t)xr * W + xc] : 0.f;
+    }
+    const int ih = ROWS * rq + wv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iw = c0 + 16 * j + lr;
+      rg.codes[j] = (ih < H1 && iw < W1) ? code1[((int64_t)b * H1 + ih) * W1 + iw] : 0ull;
+    }
+  }
+}
+
+template <typename T, bool FUSE>
+__global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict__ dp2,
                                                                 const uint8_t* __restrict__ code2,
                                                                 const T* __restrict__ wb, int H1, int W1, int H2,
-                                                                int W2, T* __restrict__ dp1,
+                                                                int W2, int n_ctiles, int n_tiles,
+                                                                T* __restrict__ dp1,
                                                                 const uint64_t* __restrict__ code1,
                                                                 const float* __restrict__ x0,
                                                                 const float* __restrict__ x1, int bsplit, int H, int W,
@@ -478,112 +539,111 @@ __global__ __launch_bounds__(256, 4) void conv2_bwd_data_kernel(const T* __restr
   float* x_s = (float*)(w_s + C2<T>::WB_ELEMS);          // FUSE only: [XROWS][XW]
   float* red = x_s + XROWS * XW;                          // FUSE only: [4][80]
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
-  const int c0 = blockIdx.x * BD_COLS, rq = blockIdx.y, b = blockIdx.z;
-  const int ih = ROWS * rq + wv;                          // this wave's output row
+  const int nrq = (H1 + ROWS - 1) / ROWS;
 
-  // ---- issue every global load of this tile first: gradient/code records, the input window, conv1's codes
-  DcStage<T, ROWS + 2, WP, true> st;
-  dc2_load(st, dp2 + (int64_t)b * H2 * W2 * 32, code2 + (int64_t)b * H2 * W2 * 32, H2, W2, ROWS * rq - 1, c0 - 1);
-  constexpr int XIT = (XROWS * XW + 255) / 256;
-  float xv[FUSE ? XIT : 1];
-  uint64_t codes[FUSE ? 4 : 1];
-  if constexpr (FUSE) {
-    const float* xb = (b < bsplit) ? x0 + (int64_t)b * H * W : x1 + (int64_t)(b - bsplit) * H * W;
+  float a1[4][4], bs[4];
 #pragma unroll
-    for (int k = 0; k < XIT; ++k) {
-      const int i = t + 256 * k;
-      const int bc = i % XW, br = i / XW;
-      const int xr = 2 * ROWS * rq - 1 + br, xc = 2 * c0 - 1 + bc;
-      xv[k] = (i < XROWS * XW && xr >= 0 && xr < H && xc >= 0 && xc < W) ? xb[(int64_t)xr * W + xc] : 0.f;
-    }
+  for (int r = 0; r < 4; ++r) {
+    bs[r] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int iw = c0 + 16 * j + lr;
-      codes[j] = (ih < H1 && iw < W1) ? code1[((int64_t)b * H1 + ih) * W1 + iw] : 0ull;
-    }
+    for (int q = 0; q < 4; ++q) a1[r][q] = 0.f;
   }
+
+  BdTileRegs<T, FUSE> rg;
+  int u = blockIdx.x;
+  if (BD_PREFETCH && u < n_tiles)
+    bd_issue<T, FUSE>(rg, u, n_ctiles, nrq, dp2, code2, H1, W1, H2, W2, code1, x0, x1, bsplit, H, W);
   copy_to_lds(w_s, wb, C2<T>::WB_ELEMS);
-  dc2_expand<T, ROWS + 2, WP, true, false>(st, ROWS * rq - 1, c0 - 1, dc_s, nullptr);
-  if constexpr (FUSE) {
+  for (; u < n_tiles; u += gridDim.x) {
+    if (!BD_PREFETCH) bd_issue<T, FUSE>(rg, u, n_ctiles, nrq, dp2, code2, H1, W1, H2, W2, code1, x0, x1, bsplit, H, W);
+    const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq, b = u / (n_ctiles * nrq);
+    const int c0 = ct * BD_COLS;
+    const int ih = ROWS * rq + wv;                          // this wave's output row
+    // ---- consume the prefetched registers into the LDS images of this tile
+    dc2_expand<T, ROWS + 2, WP, true, false>(rg.dc, ROWS * rq - 1, c0 - 1, dc_s, nullptr);
+    uint64_t codes[FUSE ? 4 : 1];
+    if constexpr (FUSE) {
 #pragma unroll
-    for (int k = 0; k < XIT; ++k) {
-      const int i = t + 256 * k;
-      if (i < XROWS * XW) x_s[i] = xv[k];
+      for (int k = 0; k < BdTileRegs<T, FUSE>::XIT; ++k) {
+        const int i = t + 256 * k;
+        if (i < XROWS * XW) x_s[i] = rg.xv[k];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) codes[j] = rg.codes[j];
     }
-  }
-  __syncthreads();
+    __syncthreads();
+    if (BD_PREFETCH && u + (int)gridDim.x < n_tiles)   // next tile's loads fly during the work below
+      bd_issue<T, FUSE>(rg, u + gridDim.x, n_ctiles, nrq, dp2, code2, H1, W1, H2, W2, code1, x0, x1, bsplit, H, W);
 
-  f32x4 acc[4];
+    f32x4 acc[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if constexpr (sizeof(T) == 2) {
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (sizeof(T) == 2) {
 #pragma unroll
-    for (int ks = 0; ks < 9; ++ks) {           // one (flipped) tap = 32 channels per k-step
-      const int ah = ks / 3, aw = ks % 3;
-      const bf16x8 a = *(const bf16x8*)&w_s[lr * KP + 32 * ks + 8 * lg];
+      for (int ks = 0; ks < 9; ++ks) {           // one (flipped) tap = 32 channels per k-step
+        const int ah = ks / 3, aw = ks % 3;
+        const bf16x8 a = *(const bf16x8*)&w_s[lr * KP + 32 * ks + 8 * lg];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bf16x8 bb = *(const bf16x8*)&dc_s[((wv + ah) * WP + 16 * j + lr + aw) * S32 + 8 * lg];
-        acc[j] = mfma16(a, bb, acc[j]);
+        for (int j = 0; j < 4; ++j) {
+          const bf16x8 bb = *(const bf16x8*)&dc_s[((wv + ah) * WP + 16 * j + lr + aw) * S32 + 8 * lg];
+          acc[j] = mfma16(a, bb, acc[j]);
+        }
       }
-    }
-  } else {
+    } else {
 #pragma unroll 2
-    for (int ks = 0; ks < 72; ++ks) {
-      const int tap = ks >> 3, o = 4 * (ks & 7) + lg;
-      const int ah = tap / 3, aw = tap % 3;
-      const float a = w_s[lr * KP + 4 * ks + lg];
+      for (int ks = 0; ks < 72; ++ks) {
+        const int tap = ks >> 3, o = 4 * (ks & 7) + lg;
+        const int ah = tap / 3, aw = tap % 3;
+        const float a = w_s[lr * KP + 4 * ks + lg];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float bb = dc_s[((wv + ah) * WP + 16 * j + lr + aw) * S32 + o];
-        acc[j] = mfma16(a, bb, acc[j]);
-      }
-    }
-  }
-  // C layout: col (lr) = pixel, row (4*lg + r) = input channel ci
-  if (dp1 != nullptr) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int iw = c0 + 16 * j + lr;
-      if (ih < H1 && iw < W1) {
-        T* dst = dp1 + (((int64_t)b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
-        if constexpr (sizeof(T) == 2) {
-          bf16x4 v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[j][r];
-          *(bf16x4*)dst = v;
-        } else {
-          *(f32x4*)dst = acc[j];
+        for (int j = 0; j < 4; ++j) {
+          const float bb = dc_s[((wv + ah) * WP + 16 * j + lr + aw) * S32 + o];
+          acc[j] = mfma16(a, bb, acc[j]);
         }
       }
     }
-  }
-  if constexpr (FUSE) {
-    float a1[4][4], bs[4];
+    // C layout: col (lr) = pixel, row (4*lg + r) = input channel ci
+    if (dp1 != nullptr) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      bs[r] = 0.f;
+      for (int j = 0; j < 4; ++j) {
+        const int iw = c0 + 16 * j + lr;
+        if (ih < H1 && iw < W1) {
+          T* dst = dp1 + (((int64_t)b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
+          if constexpr (sizeof(T) == 2) {
+            bf16x4 v;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) a1[r][q] = 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int cl = 16 * j + lr;
-      const uint64_t code = codes[j];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = 4 * lg + r;
-        const float g = ((code >> (32 + c)) & 1) ? acc[j][r] : 0.f;
-        const int pos = (int)((code >> (2 * c)) & 3);
-        const float* xp = x_s + (2 * wv + (pos >> 1)) * XW + 2 * cl + (pos & 1);
-        a1[r][0] = fmaf(g, xp[0], a1[r][0]);
-        a1[r][1] = fmaf(g, xp[1], a1[r][1]);
-        a1[r][2] = fmaf(g, xp[XW], a1[r][2]);
-        a1[r][3] = fmaf(g, xp[XW + 1], a1[r][3]);
-        bs[r] += g;
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[j][r];
+            *(bf16x4*)dst = v;
+          } else {
+            *(f32x4*)dst = acc[j];
+          }
+        }
       }
     }
-    // reduce over the 16 lanes that share a channel group, then over the 4 waves (fixed order)
+    if constexpr (FUSE) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cl = 16 * j + lr;
+        const uint64_t code = codes[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 4 * lg + r;
+          const float g = ((code >> (32 + c)) & 1) ? acc[j][r] : 0.f;
+          const int pos = (int)((code >> (2 * c)) & 3);
+          const float* xp = x_s + (2 * wv + (pos >> 1)) * XW + 2 * cl + (pos & 1);
+          a1[r][0] = fmaf(g, xp[0], a1[r][0]);
+          a1[r][1] = fmaf(g, xp[1], a1[r][1]);
+          a1[r][2] = fmaf(g, xp[XW], a1[r][2]);
+          a1[r][3] = fmaf(g, xp[XW + 1], a1[r][3]);
+          bs[r] += g;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the 16 LDS gathers of one column tile from piling up across tiles
+      }
+    }
+    __syncthreads();     // every wave is done with this tile's LDS images
+  }
+  if constexpr (FUSE) {
+    // one reduction per workgroup (not per tile): over the 16 lanes that share a channel group, then over the waves
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -597,10 +657,7 @@ __global__ __launch_bounds__(256, 4) void conv2_bwd_data_kernel(const T* __restr
       if (lr == 0) red[wv * 80 + 64 + 4 * lg + r] = v;
     }
     __syncthreads();
-    if (t < 80) {
-      const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      slabs[blk * 80 + t] = ((red[t] + red[80 + t]) + red[160 + t]) + red[240 + t];
-    }
+    if (t < 80) slabs[(int64_t)blockIdx.x * 80 + t] = ((red[t] + red[80 + t]) + red[160 + t]) + red[240 + t];
   }
 }
 
@@ -640,17 +697,21 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
   for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
     const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq, b = u / (n_ctiles * nrq);
     const int c0 = ct * COLS;
-    __syncthreads();   // previous unit's readers are done
     DcStage<T, ROWS, COLS, false> st;
+    P1Stage<T, ROWS + 2> sp;
     dc2_load(st, dp2 + (int64_t)b * H2 * W2 * 32, code2 + (int64_t)b * H2 * W2 * 32, H2, W2, ROWS * rq, c0);
-    stage_p1_band<T, ROWS + 2>(p1 + (int64_t)b * H1 * W1 * 16, H1, W1, ROWS * rq - 1, c0 - 1, p_s);
+    p1_band_load(sp, p1 + (int64_t)b * H1 * W1 * 16, H1, W1, ROWS * rq - 1, c0 - 1);
+    __syncthreads();   // previous unit's readers are done
     dc2_expand<T, ROWS, COLS, false, true>(st, ROWS * rq, c0, dc_s, bsum);
+    p1_band_store(sp, p_s);
     __syncthreads();
+    // wave wv contracts row wv of the unit (64 pixels = 2 bf16 k-steps / 16 fp32 k-steps)
+    const int d = wv;
     if constexpr (sizeof(T) == 2) {
       const int q = lr >> 2, p = lr & 3;
 #pragma unroll
-      for (int d = 0; d < ROWS; ++d) {
-        const int cb = 32 * wv + 8 * lg;   // this lane group's 8 pixels: cols cb .. cb+7 of row d
+      for (int sgm = 0; sgm < COLS / 32; ++sgm) {
+        const int cb = 32 * sgm + 8 * lg;   // this lane group's 8 pixels: cols cb .. cb+7 of row d
         bf16x8 a[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -669,39 +730,43 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
         }
       }
     } else {
-#pragma unroll 1
-      for (int d = 0; d < ROWS; ++d)
 #pragma unroll 2
-        for (int ks = 0; ks < 8; ++ks) {
-          const int cpix = 32 * wv + 4 * ks + lg;
-          float a[2];
+      for (int ks = 0; ks < COLS / 4; ++ks) {
+        const int cpix = 4 * ks + lg;
+        float a[2];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) a[i] = dc_s[(d * COLS + cpix) * S32 + 16 * i + lr];
+        for (int i = 0; i < 2; ++i) a[i] = dc_s[(d * COLS + cpix) * S32 + 16 * i + lr];
 #pragma unroll
-          for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap % 3;
-            const float bb = p_s[((d + kh) * WP + cpix + kw) * S16 + lr];
+        for (int tap = 0; tap < 9; ++tap) {
+          const int kh = tap / 3, kw = tap % 3;
+          const float bb = p_s[((d + kh) * WP + cpix + kw) * S16 + lr];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i][tap] = mfma16(a[i], bb, acc[i][tap]);
-          }
+          for (int i = 0; i < 2; ++i) acc[i][tap] = mfma16(a[i], bb, acc[i][tap]);
         }
+      }
     }
   }
-  // ---- cross-wave reduction (fixed order) and slab write.  slab layout: [o 32][tap 9][ci 16] then 32 bias sums.
+  // ---- cross-wave reduction in fixed order (wave 0 stores, waves 1..3 add in turn: each element is touched by the
+  //      same lane position in every wave) and slab write.  slab layout: [o 32][tap 9][ci 16] then 32 bias sums.
   __syncthreads();
-  float* red = (float*)dyn_smem;   // 4 waves x 4608 floats = 73.7 KB (fits the dynamic allocation, see host)
+  float* red = (float*)dyn_smem;   // 4608 floats (+ 2048 for the bias sums)
+#pragma unroll 1
+  for (int turn = 0; turn < 4; ++turn) {
+    if (wv == turn) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+        for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = 16 * i + 4 * lg + r;      // C row = M = o
-        red[wv * 4608 + (o * 9 + tap) * 16 + lr] = acc[i][tap][r];   // C col = N = ci
-      }
-  __syncthreads();
+          for (int r = 0; r < 4; ++r) {
+            const int idx = ((16 * i + 4 * lg + r) * 9 + tap) * 16 + lr;   // C row = o, C col = ci
+            red[idx] = turn == 0 ? acc[i][tap][r] : red[idx] + acc[i][tap][r];
+          }
+    }
+    __syncthreads();
+  }
   float* slab = slabs + (int64_t)blockIdx.x * (4608 + 32);
-  for (int i = t; i < 4608; i += 256) slab[i] = ((red[i] + red[4608 + i]) + red[2 * 4608 + i]) + red[3 * 4608 + i];
+  for (int i = t; i < 4608; i += 256) slab[i] = red[i];
   __syncthreads();
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[t * 8 + e] = bsum[e];
@@ -731,10 +796,13 @@ inline int conv1_slabs(int64_t total) {
   int64_t b = (total + 256 * 8 - 1) / (256 * 8);
   return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
-inline int conv2w_blocks(int n_units) { return n_units < 512 ? n_units : 512; }
+inline int conv2w_blocks(int n_units) { return n_units < 1024 ? n_units : 1024; }
 
 // Raise a kernel's dynamic-LDS limit once per process (not a stream operation: kept out of graph capture by doing it
 // on the first, un-captured launch only; the size per kernel instantiation never changes).
+inline int bd_tiles(int B, int H1, int W1) { return B * ((H1 + ROWS - 1) / ROWS) * ((W1 + BD_COLS - 1) / BD_COLS); }
+inline int bd_blocks(int n_tiles) { return n_tiles < 768 ? n_tiles : 768; }     // persistent: 3 workgroups per CU
+
 template <typename K>
 inline void allow_lds(K kernel, size_t bytes) {
   static bool done = false;    // one static per template instantiation = per kernel
@@ -833,11 +901,13 @@ int launch_bwd_data(const void* dp2, const uint8_t* code2, const void* pack, int
                     const uint64_t* code1, const float* x0, const float* x1, int bsplit, int H, int W, float* slabs,
                     hipStream_t s) {
   const int H2 = H1 / 2, W2 = W1 / 2;
-  dim3 grid((W1 + BD_COLS - 1) / BD_COLS, (H1 + ROWS - 1) / ROWS, B);
+  const int n_ctiles = (W1 + BD_COLS - 1) / BD_COLS;
+  const int n_tiles = bd_tiles(B, H1, W1);
   const size_t sm = BD<T>::lds_bytes(FUSE);
   allow_lds(conv2_bwd_data_kernel<T, FUSE>, sm);
-  hipLaunchKernelGGL((conv2_bwd_data_kernel<T, FUSE>), grid, dim3(256), sm, s, (const T*)dp2, code2,
-                     (const T*)pack + C2<T>::WF_ELEMS, H1, W1, H2, W2, (T*)dp1, code1, x0, x1, bsplit, H, W, slabs);
+  hipLaunchKernelGGL((conv2_bwd_data_kernel<T, FUSE>), dim3(bd_blocks(n_tiles)), dim3(256), sm, s, (const T*)dp2,
+                     code2, (const T*)pack + C2<T>::WF_ELEMS, H1, W1, H2, W2, n_ctiles, n_tiles, (T*)dp1, code1, x0,
+                     x1, bsplit, H, W, slabs);
   GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_data");
   return GDM_OK;
 }
@@ -846,8 +916,7 @@ int launch_bwd_data(const void* dp2, const uint8_t* code2, const void* pack, int
 extern "C" int gdm_simnn_conv2_bwd_data(const void* dp2, const uint8_t* code2, const void* pack, int B, int H1, int W1,
                                         void* dp1, int dtype, void* stream) {
   GDM_REQUIRE(dp2 && code2 && pack && dp1, "gdm_simnn_conv2_bwd_data: null pointer");
-  GDM_REQUIRE(B > 0 && B <= 65535 && H1 >= 2 && W1 >= 2 && H1 <= 65535 * ROWS && gdm_dtype_ok(dtype),
-              "gdm_simnn_conv2_bwd_data: bad arguments");
+  GDM_REQUIRE(B > 0 && H1 >= 2 && W1 >= 2 && gdm_dtype_ok(dtype), "gdm_simnn_conv2_bwd_data: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   if (dtype == GDM_BF16)
     return launch_bwd_data<__bf16, false>(dp2, code2, pack, B, H1, W1, dp1, nullptr, nullptr, nullptr, 0, 0, 0,
@@ -857,8 +926,7 @@ extern "C" int gdm_simnn_conv2_bwd_data(const void* dp2, const uint8_t* code2, c
 }
 
 extern "C" size_t gdm_simnn_conv2_bwd_fused_workspace_bytes(int B, int H1, int W1) {
-  const size_t nblocks = (size_t)B * ((H1 + ROWS - 1) / ROWS) * ((W1 + BD_COLS - 1) / BD_COLS);
-  return (nblocks + 65) * 80 * sizeof(float);
+  return (size_t)(bd_blocks(bd_tiles(B, H1, W1)) + 65) * 80 * sizeof(float);
 }
 
 extern "C" int gdm_simnn_conv2_bwd_fused(const void* dp2, const uint8_t* code2, const void* pack, int B, int H1, int W1,
@@ -866,7 +934,7 @@ extern "C" int gdm_simnn_conv2_bwd_fused(const void* dp2, const uint8_t* code2, 
                                          int W, void* dp1_or_null, int dtype, void* workspace, size_t workspace_bytes,
                                          void* stream) {
   GDM_REQUIRE(dp2 && code2 && pack && code1 && x0, "gdm_simnn_conv2_bwd_fused: null pointer");
-  GDM_REQUIRE(B > 0 && B <= 65535 && gdm_dtype_ok(dtype), "gdm_simnn_conv2_bwd_fused: bad arguments");
+  GDM_REQUIRE(B > 0 && gdm_dtype_ok(dtype), "gdm_simnn_conv2_bwd_fused: bad arguments");
   GDM_REQUIRE(H1 == (H + 1) / 2 && W1 == (W + 1) / 2 && H1 >= 2 && W1 >= 2,
               "gdm_simnn_conv2_bwd_fused: (H1,W1)=(%d,%d) does not belong to a %dx%d input", H1, W1, H, W);
   GDM_REQUIRE(bsplit >= 0 && bsplit <= B && (bsplit == B || x1 != nullptr),
@@ -893,7 +961,7 @@ extern "C" int gdm_simnn_conv2_bwd_fused_finish(int B, int H1, int W1, float* dw
     return GDM_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int nblocks = B * ((H1 + ROWS - 1) / ROWS) * ((W1 + BD_COLS - 1) / BD_COLS);
+  const int nblocks = bd_blocks(bd_tiles(B, H1, W1));
   float* slabs = (float*)workspace;
   float* scratch = slabs + (size_t)nblocks * 80;
   float* sums = scratch + 64 * 80;
@@ -922,7 +990,7 @@ extern "C" int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2,
   const int n_units = B * ((H1 + ROWS - 1) / ROWS) * n_ctiles;
   const int nblocks = conv2w_blocks(n_units);
   hipStream_t s = (hipStream_t)stream;
-  const size_t red_bytes = (size_t)4 * 4608 * sizeof(float);
+  const size_t red_bytes = (size_t)4608 * sizeof(float);
   if (dtype == GDM_BF16) {
     size_t sm = (size_t)(C2<__bf16>::DC_ELEMS + C2<__bf16>::IN_ELEMS) * 2;
     if (sm < red_bytes) sm = red_bytes;
