@@ -107,10 +107,15 @@ def build_mmgan(args, rank, dev):
     tr = MmganTrainer(mm, compute_dtype=args.dtype, elide_dead_backward=(args.mode == "elided"))
     d = synthetic.mmgan_inputs(args.batch, args.seq, seed=1234 + rank, device=dev)
 
-    def step():
+    def eager():
         return tr.step(d["piano_roll"], d["durations"], d["beats"], d["noise1"], d["noise2"], d["fake_a"],
                        d["fake_b"], g1_in_a=d["g1_in_a"], g1_in_b=d["g1_in_b"])
-    return tr, step, step
+    step = eager
+    if not args.no_graph and tr.world == 1:
+        tr.capture(d["piano_roll"], d["durations"], d["beats"], d["noise1"], d["noise2"], d["fake_a"], d["fake_b"],
+                   d["g1_in_a"], d["g1_in_b"])
+        step = tr.replay
+    return tr, step, eager
 
 
 def host_cores():
@@ -238,8 +243,7 @@ def main():
                              if args.workload == "simnn" else
                              "MMGAN (G + beat-G + D) iteration, MAESTRO-shaped synthetic (2,128,%d) rolls" % args.seq),
                 "per_gpu_batch": args.batch, "global_batch": args.batch * world, "mode": args.mode,
-                "parallelism": f"dp{world}", "launch": "eager" if (args.no_graph or world > 1 or
-                                                                    args.workload != "simnn") else "hipGraph replay",
+                "parallelism": f"dp{world}", "launch": "eager" if (args.no_graph or world > 1) else "hipGraph replay",
                 "iteration": "1 G fwd, 3 D fwd, 2 D bwd, Adam(D)" if
                 args.workload == "simnn" else "2x(G1,G2) fwd, 3 D fwd, 2 D bwd, Adam(D)",
             },

@@ -109,8 +109,16 @@ __global__ __launch_bounds__(NT) void gemm_bf16_fast(GemmArgs g) {
   __bf16* Bs = smem + IMG;
   const int t = threadIdx.x, l = t & 63, w = t >> 6, wm = w >> 1, wn = w & 1;
   const int lr = l & 15, lg = l >> 4;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * g.k_per_split;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so the MT row tiles
+  // that stream the SAME B panel (n tile, k slice) are given ids 8 apart -> they run on one XCD and share its L2.
+  const int MT = (g.M + BM - 1) / BM, NTl = (g.N + BN - 1) / BN;
+  const int id = blockIdx.x;
+  const int grp = id / (8 * MT), within = id % (8 * MT);
+  const int outer = grp * 8 + (within & 7), mt = within >> 3;
+  if (outer >= NTl * g.split_k) return;
+  const int nt = outer % NTl, zs = outer / NTl;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int kbeg = zs * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
   const TA* __restrict__ A = (const TA*)g.A;
   const TB* __restrict__ B = (const TB*)g.B;
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_fast(GemmArgs g) {
       if (n >= g.N) continue;
       f32x4 v = acc[i][j];
       if (g.split_k > 1) {
-        float* dst = g.ws + ((int64_t)blockIdx.z * g.M + m) * g.N + n;
+        float* dst = g.ws + ((int64_t)zs * g.M + m) * g.N + n;
         if (vec_ok) *(f32x4*)dst = v;
         else
           for (int r = 0; r < 4 && n + r < g.N; ++r) dst[r] = v[r];
@@ -225,7 +233,9 @@ int gdm_gemm_bf16_fast_launch(const GemmArgs& g, int a_dtype, int b_dtype, hipSt
   bool ak = true, bk = true;
   operand_ok(g.A, a_dtype, g.sam, g.sak, &ak);
   operand_ok(g.B, b_dtype, g.sbn, g.sbk, &bk);
-  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.split_k);
+  const int MT = (g.M + BM - 1) / BM, NTl = (g.N + BN - 1) / BN;
+  const int outer = NTl * g.split_k;
+  dim3 grid((unsigned)(((outer + 7) / 8) * 8 * MT));
   if (a_dtype == GDM_BF16) {
     if (ak) launch_a<__bf16, true>(g, b_dtype, bk, grid, s); else launch_a<__bf16, false>(g, b_dtype, bk, grid, s);
   } else {

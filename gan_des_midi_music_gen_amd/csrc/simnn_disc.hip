@@ -49,27 +49,37 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
     uint64_t code = 0;
     T outv[16];
+    // two channels per packed-fp32 instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_max_f32): the stencil is VALU-bound
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      const float w00 = w[c * 4 + 0], w01 = w[c * 4 + 1], w10 = w[c * 4 + 2], w11 = w[c * 4 + 3], bc = bias[c];
-      float best = 0.f;
-      int bi = 0;
+    for (int cp = 0; cp < 8; ++cp) {
+      const int c = 2 * cp;
+      const f32x2 w00 = {w[c * 4 + 0], w[c * 4 + 4]}, w01 = {w[c * 4 + 1], w[c * 4 + 5]};
+      const f32x2 w10 = {w[c * 4 + 2], w[c * 4 + 6]}, w11 = {w[c * 4 + 3], w[c * 4 + 7]};
+      const f32x2 bc = {bias[c], bias[c + 1]};
+      f32x2 v[4];
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-          // same accumulation order as a k-ordered dot product: ((b + w00*x00) + w01*x01) + ...
-          float v = in[dy][dx] * w00;
-          v = fmaf(in[dy][dx + 1], w01, v);
-          v = fmaf(in[dy + 1][dx], w10, v);
-          v = fmaf(in[dy + 1][dx + 1], w11, v);
-          v += bc;
-          v = v > 0.f ? v : 0.f;
-          if ((dy == 0 && dx == 0) || v > best) { best = v; bi = dy * 2 + dx; }
+          // same accumulation order as a k-ordered dot product, bias added last (as aten's conv does)
+          f32x2 acc = (f32x2){in[dy][dx], in[dy][dx]} * w00;
+          acc = __builtin_elementwise_fma((f32x2){in[dy][dx + 1], in[dy][dx + 1]}, w01, acc);
+          acc = __builtin_elementwise_fma((f32x2){in[dy + 1][dx], in[dy + 1][dx]}, w10, acc);
+          acc = __builtin_elementwise_fma((f32x2){in[dy + 1][dx + 1], in[dy + 1][dx + 1]}, w11, acc);
+          acc += bc;
+          v[dy * 2 + dx] = __builtin_elementwise_max(acc, (f32x2){0.f, 0.f});
         }
-      outv[c] = from_f32<T>(best);
-      code |= (uint64_t)bi << (2 * c);
-      if (best > 0.f) code |= 1ull << (32 + c);
+      const f32x2 best2 = __builtin_elementwise_max(__builtin_elementwise_max(v[0], v[1]),
+                                                    __builtin_elementwise_max(v[2], v[3]));
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float best = best2[e];
+        // first position (scan order) that attains the maximum == aten's strict '>' scan
+        const int bi = v[0][e] == best ? 0 : (v[1][e] == best ? 1 : (v[2][e] == best ? 2 : 3));
+        outv[c + e] = from_f32<T>(best);
+        code |= (uint64_t)bi << (2 * (c + e));
+        if (best > 0.f) code |= 1ull << (32 + c + e);
+      }
     }
     T* o = p1 + idx * 16;
     if constexpr (sizeof(T) == 2) {

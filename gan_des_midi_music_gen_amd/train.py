@@ -317,6 +317,33 @@ class MmganTrainer(_TrainerBase):
         return self.loss_d, self.loss_g
 
 
+    # ---- hipGraph capture for fixed input buffers --------------------------------------------------------------------
+    def capture(self, piano_roll, durations, beats, noise1, noise2, fake_a, fake_b, g1_in_a, g1_in_b):
+        """Record one iteration on fixed tensors into a hipGraph (the iteration is ~130 small launches: replay removes
+        the host launch cost).  Needs tensor bridge outputs, explicit generator-1 inputs (the reference draws them on
+        the CPU generator, network_tests.py:83-84, which cannot be part of a device graph) and a single rank."""
+        args = (piano_roll, durations, beats, noise1, noise2, fake_a, fake_b, g1_in_a, g1_in_b)
+        if any(callable(a) for a in args) or any(a is None for a in args) or self.world > 1:
+            raise ops.GdmError("graph capture needs tensor inputs (incl. g1_in_a/g1_in_b) and a single rank")
+        self._static = args
+        warm = torch.cuda.Stream(piano_roll.device)
+        warm.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(warm):
+            for _ in range(2):
+                self.step(*args[:7], g1_in_a=g1_in_a, g1_in_b=g1_in_b)
+        torch.cuda.current_stream().wait_stream(warm)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self.step(*args[:7], g1_in_a=g1_in_a, g1_in_b=g1_in_b)
+        return self._graph
+
+    def replay(self):
+        self._graph.replay()
+        self.iterations += 1
+        return self.loss_d, self.loss_g
+
+
 class StepLR:
     """torch.optim.lr_scheduler.StepLR(step_size, gamma) for a trainer (network_tests.py:257-258, 328-329)."""
 
