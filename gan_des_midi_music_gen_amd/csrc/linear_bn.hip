@@ -1,0 +1,173 @@
+// One generator block of model 2 in one launch: Linear -> BatchNorm1d (train or eval) -> activation
+// (MMGAN_MIDI_DES/network_tests.py:75-80, 110-115), for batches of up to 256 rows.
+//
+// A 256-thread workgroup owns ALL M rows of a 32-column strip of the output, so the batch statistics of its columns
+// never leave the workgroup: y = x W^T + b is accumulated on v_mfma_f32_16x16x32_bf16 (wave w: rows [64w, 64w+64),
+// 4 x 2 accumulator tiles), the column mean is reduced registers -> lanes -> waves (LDS), the variance is a second pass
+// over the SAME registers (exact two-pass, no E[x^2]-E[x]^2 cancellation), running statistics are updated by the
+// owning workgroup, and the normalised + activated strip is stored.  Replaces GEMM + 3 batch-norm launches per layer.
+#include "gdm_common.h"
+
+namespace {
+
+constexpr int LB_M = 256, LB_N = 32, LB_KT = 32, LB_LD = LB_KT + 8;
+
+__global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var,
+                                                            int64_t* __restrict__ nbt, float momentum, float eps,
+                                                            int act, int training, int M, int N, int K,
+                                                            float* __restrict__ y_out, float* __restrict__ out,
+                                                            float* __restrict__ save_mean,
+                                                            float* __restrict__ save_invstd) {
+  __shared__ __attribute__((aligned(16))) __bf16 As[LB_M * LB_LD];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[LB_N * LB_LD];
+  __shared__ float colred[4][LB_N];
+  __shared__ float colstat[2][LB_N];
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
+  const int n0 = blockIdx.x * LB_N;
+  if (blockIdx.x == 0 && t == 0 && training && nbt) nbt[0] += 1;
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < K; k0 += LB_KT) {
+    // stage x (256 x 32) and W (32 x 32), fp32 -> bf16; lanes run along k (both operands are k-contiguous)
+#pragma unroll
+    for (int i = 0; i < LB_M * LB_KT / 256; ++i) {
+      const int idx = t + 256 * i, m = idx / LB_KT, k = idx % LB_KT;
+      const float v = (m < M && k0 + k < K) ? x[(int64_t)m * K + k0 + k] : 0.f;
+      As[m * LB_LD + k] = (__bf16)v;
+    }
+#pragma unroll
+    for (int i = 0; i < LB_N * LB_KT / 256; ++i) {
+      const int idx = t + 256 * i, n = idx / LB_KT, k = idx % LB_KT;
+      const float v = (n0 + n < N && k0 + k < K) ? w[(int64_t)(n0 + n) * K + k0 + k] : 0.f;
+      Bs[n * LB_LD + k] = (__bf16)v;
+    }
+    __syncthreads();
+    bf16x8 b[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8*)&Bs[(16 * j + lr) * LB_LD + 8 * lg];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16x8 a = *(const bf16x8*)&As[(64 * wv + 16 * i + lr) * LB_LD + 8 * lg];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a, b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  // C layout: col = n (16j + lr), row = m (64wv + 16i + 4lg + r).  Add the Linear bias.
+  float bn_[2], mean[2], invstd[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + 16 * j + lr;
+    bn_[j] = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] += bn_[j];
+  }
+  if (training) {
+    // ---- pass 1: column means over the M valid rows
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += (64 * wv + 16 * i + 4 * lg + r < M) ? acc[i][j][r] : 0.f;
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lg == 0) colred[wv][16 * j + lr] = s;
+    }
+    __syncthreads();
+    if (t < LB_N) colstat[0][t] = (((colred[0][t] + colred[1][t]) + colred[2][t]) + colred[3][t]) / (float)M;
+    __syncthreads();
+    // ---- pass 2: centred sum of squares from the same registers
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      mean[j] = colstat[0][16 * j + lr];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dlt = acc[i][j][r] - mean[j];
+          s += (64 * wv + 16 * i + 4 * lg + r < M) ? dlt * dlt : 0.f;
+        }
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      if (lg == 0) colred[wv][16 * j + lr] = s;
+    }
+    __syncthreads();
+    if (t < LB_N) {
+      const float m2 = ((colred[0][t] + colred[1][t]) + colred[2][t]) + colred[3][t];
+      const float var_b = m2 / (float)M;
+      colstat[1][t] = 1.0f / sqrtf(var_b + eps);
+      const int n = n0 + t;
+      if (n < N) {
+        save_mean[n] = colstat[0][t];
+        save_invstd[n] = colstat[1][t];
+        if (running_mean) {
+          running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * colstat[0][t];
+          running_var[n] = (1.f - momentum) * running_var[n] + momentum * (m2 / (float)max(M - 1, 1));
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) invstd[j] = colstat[1][16 * j + lr];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + 16 * j + lr;
+      mean[j] = n < N ? running_mean[n] : 0.f;
+      invstd[j] = n < N ? 1.0f / sqrtf(running_var[n] + eps) : 0.f;
+      if (n < N && lg == 0 && wv == 0) { save_mean[n] = mean[j]; save_invstd[n] = invstd[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + 16 * j + lr;
+    if (n >= N) continue;
+    const float alpha = invstd[j] * gamma[n], bt = beta[n];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 64 * wv + 16 * i + 4 * lg + r;
+        if (m < M) {
+          const float yv = acc[i][j][r];
+          if (y_out) y_out[(int64_t)m * N + n] = yv;
+          out[(int64_t)m * N + n] = apply_act((yv - mean[j]) * alpha + bt, act, 0.f);
+        }
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int gdm_linear_bn_act_max_rows(void) { return LB_M; }
+
+extern "C" int gdm_linear_bn_act_fwd(const float* x, const float* w, const float* bias, const float* gamma,
+                                     const float* beta, float* running_mean, float* running_var,
+                                     int64_t* num_batches_tracked, float momentum, float eps, int act, int training,
+                                     int M, int N, int K, float* y_out, float* out, float* save_mean,
+                                     float* save_invstd, void* stream) {
+  GDM_REQUIRE(x && w && gamma && beta && out && save_mean && save_invstd, "gdm_linear_bn_act_fwd: null pointer");
+  GDM_REQUIRE(M >= 1 && M <= LB_M && N >= 1 && K >= 1, "gdm_linear_bn_act_fwd: M=%d outside 1..%d (or bad N/K)", M, LB_M);
+  GDM_REQUIRE(!training || M > 1, "gdm_linear_bn_act_fwd: training-mode batch norm needs more than 1 row");
+  GDM_REQUIRE(training || (running_mean && running_var), "gdm_linear_bn_act_fwd: eval mode needs running statistics");
+  hipLaunchKernelGGL(linear_bn_act_kernel, dim3((N + LB_N - 1) / LB_N), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                     gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, act, training, M, N, K,
+                     y_out, out, save_mean, save_invstd);
+  GDM_LAUNCH_OK("gdm_linear_bn_act_fwd");
+  return GDM_OK;
+}

@@ -253,14 +253,22 @@ class SimnnGenFn(torch.autograd.Function):
 # ======================================================================================================================
 # Model 2 generators: 4 x [Linear -> BatchNorm1d -> Sigmoid] (MMGAN_MIDI_DES/network_tests.py:67-80, 102-115)
 # ======================================================================================================================
-def mlp_bn_sigmoid_forward(x, layers, training, dt):
-    """layers: list of (W (out,in), b, gamma, beta, rmean, rvar, nbt).  Returns (out fp32, saved)."""
+def mlp_bn_sigmoid_forward(x, layers, training, dt, need_backward=True):
+    """layers: list of (W (out,in), b, gamma, beta, rmean, rvar, nbt).  Returns (out fp32, saved).
+
+    bf16 mode with <= 256 rows: one fused Linear+BN+Sigmoid launch per block (batch statistics never leave the
+    workgroup); otherwise GEMM + the three-launch batch norm (any batch size, exact-fp32 mode)."""
     saved = []
     x = _f32c(x)
+    fused = dt == BF16 and x.shape[0] <= ops.linear_bn_act_max_rows() and (not training or x.shape[0] > 1)
     for (w, bias, gamma, beta, rm, rv, nbt) in layers:
-        y = ops.gemm(x, w.t(), bias_n=bias, compute=dt)
-        out, mean, invstd = ops.bn_act_fwd(y, gamma, beta, rm, rv, nbt, act=ACT_SIGMOID, out_dtype=F32,
-                                           training=training)
+        if fused:
+            out, y, mean, invstd = ops.linear_bn_act_fwd(x, w, bias, gamma, beta, rm, rv, nbt, act=ACT_SIGMOID,
+                                                         training=training, save_y=need_backward)
+        else:
+            y = ops.gemm(x, w.t(), bias_n=bias, compute=dt)
+            out, mean, invstd = ops.bn_act_fwd(y, gamma, beta, rm, rv, nbt, act=ACT_SIGMOID, out_dtype=F32,
+                                               training=training)
         saved.append((x, y, out, mean, invstd))
         x = out
     return x, saved

@@ -374,6 +374,85 @@ def simnn_head(h1, w2, b2, n0, y0, y1, *, loss_out, accumulate_loss=False, want_
     return prob, dh1, ((dw2, db2, db1) if want_grad else None)
 
 
+# ------------------------------------------------------------------------------------------ model 2 fused kernels
+def linear_bn_act_max_rows():
+    return _lib.load().gdm_linear_bn_act_max_rows()
+
+
+def linear_bn_act_fwd(x, w, bias, gamma, beta, running_mean, running_var, nbt, *, act, training=True, momentum=0.1,
+                      eps=1e-5, save_y=False):
+    """Linear + BatchNorm1d + activation in one launch (rows <= linear_bn_act_max_rows()).
+    Returns (out, y or None, save_mean, save_invstd)."""
+    _need_gpu(x, w, bias, gamma, beta, running_mean, running_var, nbt)
+    assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.is_contiguous() and w.is_contiguous()
+    assert x.dtype == torch.float32 and w.dtype == torch.float32
+    m, k = x.shape
+    n = w.shape[0]
+    out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device) if save_y else None
+    mean = torch.empty(n, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(n, dtype=torch.float32, device=x.device)
+    _call("gdm_linear_bn_act_fwd", _p(x), _p(w), _p(bias), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+          _p(nbt), float(momentum), float(eps), act, 1 if training else 0, m, n, k, _p(y), _p(out), _p(mean),
+          _p(invstd), _stream())
+    return out, y, mean, invstd
+
+
+def dcnn_fused_supported(t):
+    return bool(_lib.load().gdm_dcnn_fused_supported(int(t)))
+
+
+def dcnn_pack(w1, b1, w2, b2, wfc, bfc, t, out=None):
+    """bf16 MFMA weight images + permuted fc weight + biases for dcnn_fused; refresh after every weight update."""
+    _need_gpu(w1, b1, w2, b2, wfc, bfc, out)
+    for a in (w1, b1, w2, b2, wfc, bfc):
+        assert a.dtype == torch.float32 and a.is_contiguous()
+    nbytes = _lib.load().gdm_dcnn_pack_bytes(int(t))
+    pack = out if out is not None else torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+    assert pack.numel() == nbytes
+    _call("gdm_dcnn_pack", _p(w1), _p(b1), _p(w2), _p(b2), _p(wfc), _p(bfc), int(t), _p(pack), _stream())
+    return pack
+
+
+def dcnn_fused(xa, planes, t, ya, yb, pack, *, loss_out, accumulate_loss=False, want_grad=True, grad_out=None):
+    """DiscriminatorCNN forward + BCE loss (+ backward) in one persistent kernel.
+
+    xa: (Ba,2,128,T) fp32 contiguous or None (label ya); planes: (p0, p1) each (Bb,128,T) or None (label yb).
+    grad_out: 6 tensors (dw1, db1, dw2, db2, dwfc, dbfc) to fill.  Returns (logits (B,), grads or None)."""
+    _need_gpu(xa, pack, loss_out)
+    ba = 0 if xa is None else xa.shape[0]
+    p0 = p1 = None
+    bb = 0
+    if planes is not None:
+        p0, p1 = planes
+        _need_gpu(p0, p1)
+        assert p0.is_contiguous() and p1.is_contiguous() and p0.shape == p1.shape and p0.shape[1:] == (128, t)
+        assert p0.dtype == torch.float32 and p1.dtype == torch.float32
+        bb = p0.shape[0]
+    if xa is not None:
+        assert xa.is_contiguous() and xa.dtype == torch.float32 and xa.shape[1:] == (2, 128, t)
+    b = ba + bb
+    dev = pack.device
+    logits = torch.empty(b, dtype=torch.float32, device=dev)
+    grads = None
+    if want_grad:
+        if grad_out is not None:
+            grads = list(grad_out)
+        else:
+            k = 32 * 32 * (((t // 2) - 2) // 2 + 1)
+            grads = [torch.empty(s, dtype=torch.float32, device=dev)
+                     for s in ((16, 2, 4, 4), (16,), (32, 16, 4, 4), (32,), (1, k), (1,))]
+        for g in grads:
+            assert g.is_contiguous() and g.dtype == torch.float32
+    lib = _lib.load()
+    nb = lib.gdm_dcnn_fused_workspace_bytes(b, int(t), 1 if want_grad else 0)
+    ws = workspace(nb, dev)
+    gp = [_p(g) for g in grads] if grads else [None] * 6
+    _call("gdm_dcnn_fused", _p(xa), ba, _p(p0), _p(p1), b, int(t), float(ya), float(yb), _p(pack), _p(logits),
+          _p(loss_out), 1 if accumulate_loss else 0, 1 if want_grad else 0, *gp, _p(ws), nb, _stream())
+    return logits, grads
+
+
 # ------------------------------------------------------------------------------------------ patch lowering
 def im2col(src, *, planar, b, h, w, c, kh, kw, stride, pad, out_dtype):
     _need_gpu(src)

@@ -251,7 +251,12 @@ class SimnnTrainer(_TrainerBase):
 
 
 class MmganTrainer(_TrainerBase):
-    """``step`` = one iteration of network_tests.py:281-321 for a MultiModalGAN."""
+    """``step`` = one iteration of network_tests.py:281-321 for a MultiModalGAN.
+
+    bf16 mode (and a roll length the kernel supports, T = 50 does): the discriminator's forward, loss and backward run
+    as ONE persistent kernel per pass that keeps a sample and all its activations in LDS (``ops.dcnn_fused``), and each
+    generator block is one fused Linear+BatchNorm+Sigmoid launch.  fp32 mode: GEMM + im2col lowering (parity path).
+    """
 
     def __init__(self, mmgan, lr=0.01, betas=(0.9, 0.999), eps=1e-8, compute_dtype=None, elide_dead_backward=False,
                  process_group=None):
@@ -260,6 +265,11 @@ class MmganTrainer(_TrainerBase):
         self._init_common([d.conv1.weight, d.conv1.bias, d.conv2.weight, d.conv2.bias, d.fc.weight, d.fc.bias], lr,
                           betas, eps, compute_dtype, elide_dead_backward, process_group)
         self.last_g1 = self.last_g2 = None
+        self._pack = None          # packed weight images of the fused discriminator kernel (persistent buffer)
+        self._graph = None
+
+    def invalidate_weights(self):
+        self._pack = None
 
     @staticmethod
     def _layers(gen):
@@ -272,10 +282,15 @@ class MmganTrainer(_TrainerBase):
             g1_input = torch.randn(len(noise1), mm.generator1.input_tensor_dim).to(noise1.device)
         x1 = torch.cat((noise1, g1_input), dim=1)
         x2 = torch.cat((noise2, beats), dim=1)
-        o1, _ = Fn.mlp_bn_sigmoid_forward(x1, self._layers(mm.generator1), mm.generator1.training, dt)
-        o2, _ = Fn.mlp_bn_sigmoid_forward(x2, self._layers(mm.generator2), mm.generator2.training, dt)
+        o1, _ = Fn.mlp_bn_sigmoid_forward(x1, self._layers(mm.generator1), mm.generator1.training, dt,
+                                          need_backward=False)
+        o2, _ = Fn.mlp_bn_sigmoid_forward(x2, self._layers(mm.generator2), mm.generator2.training, dt,
+                                          need_backward=False)
         a = mm.generator1.adj_size
         return o1.view(len(noise1), -1, a[0], a[1]), o2
+
+    def _fused_ok(self, t):
+        return self.dt == ops.BF16 and ops.dcnn_fused_supported(t)
 
     @torch.no_grad()
     def step(self, piano_roll, durations, beats, noise1, noise2, fake_a, fake_b, g1_in_a=None, g1_in_b=None):
@@ -283,39 +298,60 @@ class MmganTrainer(_TrainerBase):
         DES bridge of the D-step and G-step forwards (network_tests.py:294, 312)."""
         dt = self.dt
         w1, b1, w2, b2, wf, bf = self.d.views
+        gv = self.d.grad_views
         b = piano_roll.shape[0]
+        t = piano_roll.shape[2]
         dev = piano_roll.device
+        fused = self._fused_ok(t)
         # --- D step (network_tests.py:293-308)
         g1, g2 = self._generators_forward(noise1, noise2, beats, g1_in_a)
         self.last_g1, self.last_g2 = g1, g2
         if callable(fake_a):
             fake_a = fake_a(g1, g2)
-        x = torch.empty((2 * b, 2) + tuple(piano_roll.shape[1:]), dtype=torch.float32, device=dev)
-        x[:b].copy_(fake_a)                        # [fake ; real]: same order as the two loss terms (304-305)
-        x[b:, 0].copy_(piano_roll)                 # real_data = stack([roll, dur]).permute(1,0,2,3) (290)
-        x[b:, 1].copy_(durations)
-        logits, saved = Fn.dcnn_forward(x, w1, b1, w2, b2, wf, bf, dt)
-        lg = logits.view(-1)
-        dl = torch.empty(2 * b, dtype=torch.float32, device=dev)
-        ops.bce_with_logits(lg[:b], 0.0, loss_out=self.loss_d, dx_out=dl[:b])
-        ops.bce_with_logits(lg[b:], 1.0, loss_out=self.loss_d, dx_out=dl[b:], accumulate_loss=True)
-        grads = Fn.dcnn_backward(saved, dl, w2, wf, dt)
-        for gv, g in zip(self.d.grad_views, grads):
-            gv.copy_(g.view(gv.shape))
+        if fused:
+            if self._pack is None:
+                self._pack = ops.dcnn_pack(w1, b1, w2, b2, wf, bf, t)
+            fa = Fn._f32c(fake_a)
+            # batch [fake ; real] with labels 0 / 1 (304-305); real_data is read as two planes: no stack/permute copy
+            ops.dcnn_fused(fa, (Fn._f32c(piano_roll), Fn._f32c(durations)), t, 0.0, 1.0, self._pack,
+                           loss_out=self.loss_d, grad_out=gv)
+        else:
+            x = torch.empty((2 * b, 2) + tuple(piano_roll.shape[1:]), dtype=torch.float32, device=dev)
+            x[:b].copy_(fake_a)                        # [fake ; real]: same order as the two loss terms (304-305)
+            x[b:, 0].copy_(piano_roll)                 # real_data = stack([roll, dur]).permute(1,0,2,3) (290)
+            x[b:, 1].copy_(durations)
+            logits, saved = Fn.dcnn_forward(x, w1, b1, w2, b2, wf, bf, dt)
+            lg = logits.view(-1)
+            dl = torch.empty(2 * b, dtype=torch.float32, device=dev)
+            ops.bce_with_logits(lg[:b], 0.0, loss_out=self.loss_d, dx_out=dl[:b])
+            ops.bce_with_logits(lg[b:], 1.0, loss_out=self.loss_d, dx_out=dl[b:], accumulate_loss=True)
+            grads = Fn.dcnn_backward(saved, dl, w2, wf, dt)
+            for gview, g in zip(gv, grads):
+                gview.copy_(g.view(gview.shape))
         self._reduce_and_step()
+        if fused:
+            ops.dcnn_pack(w1, b1, w2, b2, wf, bf, t, out=self._pack)     # weights changed: refresh in place
         # --- "G" step (311-315): both generators run again (2nd BN statistics update), D forward on the new fake
         g1b, g2b = self._generators_forward(noise1, noise2, beats, g1_in_b)
         if callable(fake_b):
             fake_b = fake_b(g1b, g2b)
-        logits_g, saved_g = Fn.dcnn_forward(fake_b, w1, b1, w2, b2, wf, bf, dt)
-        if self.elide:
-            ops.bce_with_logits(logits_g.view(-1), 1.0, loss_out=self.loss_g, want_grad=False)
+        if fused:
+            if self.elide:
+                ops.dcnn_fused(Fn._f32c(fake_b), None, t, 1.0, 1.0, self._pack, loss_out=self.loss_g, want_grad=False)
+            else:   # dead values (only D's .grad in the reference, wiped by the next zero_grad): scratch buffers
+                if getattr(self, "_scratch_grads", None) is None:
+                    self._scratch_grads = [torch.empty_like(g) for g in gv]
+                ops.dcnn_fused(Fn._f32c(fake_b), None, t, 1.0, 1.0, self._pack, loss_out=self.loss_g,
+                               grad_out=self._scratch_grads)
         else:
-            _, dlg = ops.bce_with_logits(logits_g.view(-1), 1.0, loss_out=self.loss_g)
-            Fn.dcnn_backward(saved_g, dlg, w2, wf, dt)     # dead values (only D's .grad in the reference)
+            logits_g, saved_g = Fn.dcnn_forward(fake_b, w1, b1, w2, b2, wf, bf, dt)
+            if self.elide:
+                ops.bce_with_logits(logits_g.view(-1), 1.0, loss_out=self.loss_g, want_grad=False)
+            else:
+                _, dlg = ops.bce_with_logits(logits_g.view(-1), 1.0, loss_out=self.loss_g)
+                Fn.dcnn_backward(saved_g, dlg, w2, wf, dt)     # dead values (only D's .grad in the reference)
         self.iterations += 1
         return self.loss_d, self.loss_g
-
 
     # ---- hipGraph capture for fixed input buffers --------------------------------------------------------------------
     def capture(self, piano_roll, durations, beats, noise1, noise2, fake_a, fake_b, g1_in_a, g1_in_b):

@@ -150,6 +150,35 @@ int gdm_simnn_head(const float* h1, const float* w2, const float* b2, int n, int
                    float* loss, int accumulate_loss, float* dh1, float* dw2, float* db2, float* db1, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* ---- model 2 -----------------------------------------------------------------------------------------------------
+ * One generator block in one launch: out = act(BatchNorm1d(x W^T + b)) for up to gdm_linear_bn_act_max_rows() rows
+ * (network_tests.py:75-80,110-115: aten::addmm + native_batch_norm + sigmoid).  x (M,K), w (N,K) fp32 row-major;
+ * bf16 MFMA operands, fp32 accumulation, exact two-pass batch statistics kept inside the workgroup that owns the
+ * columns; running statistics / num_batches_tracked updated in training mode.  y_out (M,N) = pre-norm values,
+ * optional (backward needs them).                                                                                    */
+int gdm_linear_bn_act_max_rows(void);
+int gdm_linear_bn_act_fwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                          float eps, int act, int training, int M, int N, int K, float* y_out, float* out,
+                          float* save_mean, float* save_invstd, void* stream);
+/* DiscriminatorCNN(roll_size=(2,128,T)) forward + BCE-with-logits loss + full backward as one persistent kernel that
+ * keeps a whole sample and its activations in LDS (network_tests.py:147-160 and the criterion calls at 304-305, 313;
+ * replaces aten::convolution x2, leaky_relu x2, addmm, binary_cross_entropy_with_logits and their backwards).
+ * Samples [0,bsplit) are read from xa (bsplit,2,128,T) with label ya; samples [bsplit,B) from the two planes p0, p1
+ * (B-bsplit,128,T) (piano_roll, durations: the reference's stack().permute() view, network_tests.py:290) with label
+ * yb.  loss[0] (+)= mean_a + mean_b; logits (B).  want_grad: dw1 (16,2,4,4), db1, dw2 (32,16,4,4), db2, dwfc (1,K),
+ * dbfc.  Weights come from gdm_dcnn_pack (bf16 MFMA images + permuted fc weight + biases; rebuild after every update).
+ * bf16 only; gdm_dcnn_fused_supported(T) tells whether the roll length fits (T = 50: yes).                           */
+int gdm_dcnn_fused_supported(int T);
+size_t gdm_dcnn_pack_bytes(int T);
+int gdm_dcnn_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* wfc,
+                  const float* bfc, int T, void* pack, void* stream);
+size_t gdm_dcnn_fused_workspace_bytes(int B, int T, int want_grad);
+int gdm_dcnn_fused(const float* xa, int bsplit, const float* p0, const float* p1, int B, int T, float ya, float yb,
+                   const void* pack, float* logits, float* loss, int accumulate_loss, int want_grad, float* dw1,
+                   float* db1, float* dw2, float* db2, float* dwfc, float* dbfc, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
 /* ---- generic convolution lowering helpers (model 2 discriminator, model 1 generator) ----------------------------
  * im2col for Conv2d fwd / dW and col2im (gather form, deterministic) for Conv2d dX and ConvTranspose2d fwd.
  * Activations are channels-last (B,H,W,C) unless `src_planar` (NCHW fp32 input planes, e.g. the piano-roll).

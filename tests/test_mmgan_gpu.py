@@ -171,6 +171,98 @@ def test_dcnn_vs_oracle(mode, tol_out, tol_grad, t):
         assert rel_l2(pg.grad, pr.grad) < tol_grad, (k, rel_l2(pg.grad, pr.grad))
 
 
+def test_fused_dcnn_kernel_vs_oracle_bf16():
+    """The one-kernel discriminator pass (forward + BCE + backward, everything in LDS) against the CPU oracle."""
+    from gan_des_midi_music_gen_amd import ops
+    t, b = 50, 6
+    assert ops.dcnn_fused_supported(t) and not ops.dcnn_fused_supported(256)
+    torch.manual_seed(8)
+    ref = om.DiscriminatorCNN(roll_size=(2, 128, t))
+    d = synthetic.mmgan_inputs(b, t, seed=31)
+    real_data = torch.stack([d["piano_roll"], d["durations"]]).permute(1, 0, 2, 3)
+    lo_f, lo_r = ref(d["fake_a"]), ref(real_data)
+    loss = ost.bce_with_logits(lo_f.squeeze(), torch.zeros(b)) + ost.bce_with_logits(lo_r.squeeze(), torch.ones(b))
+    loss.backward()
+    ps = [p.detach().to(DEV).contiguous() for p in ref.parameters()]       # conv1.w, conv1.b, conv2.w, conv2.b, fc.w, fc.b
+    pack = ops.dcnn_pack(*ps, t)
+    lo = torch.zeros(1, device=DEV)
+    logits, grads = ops.dcnn_fused(d["fake_a"].to(DEV), (d["piano_roll"].to(DEV), d["durations"].to(DEV)), t, 0.0, 1.0,
+                                   pack, loss_out=lo)
+    want_logits = torch.cat([lo_f, lo_r]).reshape(-1)
+    _close(logits, want_logits, 2e-2, "fused DCNN logits")
+    assert abs(lo.item() - loss.item()) < 2e-2 * max(1.0, abs(loss.item()))
+    for (k, pr), g in zip(ref.named_parameters(), grads):
+        # bias gradients are sums of ~10^4 signed bf16-rounded terms with heavy cancellation: 1e-1; weights 5e-2
+        tol = 1e-1 if k.endswith("bias") else 5e-2
+        assert rel_l2(g.reshape(pr.shape), pr.grad) < tol, (k, rel_l2(g.reshape(pr.shape), pr.grad))
+    # determinism + forward-only variant + a batch that gives several samples to one workgroup
+    logits2, grads2 = ops.dcnn_fused(d["fake_a"].to(DEV), (d["piano_roll"].to(DEV), d["durations"].to(DEV)), t, 0.0,
+                                     1.0, pack, loss_out=lo)
+    assert torch.equal(logits, logits2) and all(torch.equal(a, c) for a, c in zip(grads, grads2))
+    lo_only = torch.zeros(1, device=DEV)
+    logits3, none = ops.dcnn_fused(d["fake_a"].to(DEV), None, t, 1.0, 1.0, pack, loss_out=lo_only, want_grad=False)
+    assert none is None and torch.equal(logits3, logits[:b])
+    want = ost.bce_with_logits(lo_f.squeeze().detach(), torch.ones(b)).item()
+    assert abs(lo_only.item() - want) < 2e-2 * max(1.0, abs(want))
+    big = synthetic.mmgan_inputs(600, t, seed=32, device=DEV)
+    lg_big, g_big = ops.dcnn_fused(big["fake_a"], None, t, 1.0, 1.0, pack, loss_out=lo)
+    lg_parts = torch.cat([ops.dcnn_fused(big["fake_a"][i:i + 200].contiguous(), None, t, 1.0, 1.0, pack, loss_out=lo,
+                                         want_grad=False)[0] for i in (0, 200, 400)])
+    assert torch.equal(lg_big, lg_parts)
+
+
+def test_fused_linear_bn_sigmoid_matches_unfused_path():
+    from gan_des_midi_music_gen_amd import ops
+    g = torch.Generator().manual_seed(12)
+    for m, k, n in ((256, 100, 256), (16, 64, 4096), (37, 128, 20)):
+        x = torch.randn(m, k, generator=g)
+        lin = torch.nn.Linear(k, n)
+        bn = torch.nn.BatchNorm1d(n)
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_()
+        want = torch.sigmoid(bn(lin(x)))
+        rm, rv = torch.zeros(n, device=DEV), torch.ones(n, device=DEV)
+        nbt = torch.zeros((), dtype=torch.long, device=DEV)
+        out, y, mean, invstd = ops.linear_bn_act_fwd(x.to(DEV), lin.weight.detach().to(DEV), lin.bias.detach().to(DEV),
+                                                     bn.weight.detach().to(DEV), bn.bias.detach().to(DEV), rm, rv, nbt,
+                                                     act=ops.ACT_SIGMOID, save_y=True)
+        _close(out, want, 2e-2, f"fused linear+bn+sigmoid {m}x{k}x{n}")
+        _close(rm, bn.running_mean, 2e-2, "running mean")
+        _close(rv, bn.running_var, 3e-2, "running var")
+        _close(y, lin(x), 1e-2, "pre-norm values")
+        assert int(nbt.item()) == 1
+        bn.eval()
+        out_e, _, _, _ = ops.linear_bn_act_fwd(x.to(DEV), lin.weight.detach().to(DEV), lin.bias.detach().to(DEV),
+                                               bn.weight.detach().to(DEV), bn.bias.detach().to(DEV),
+                                               bn.running_mean.to(DEV), bn.running_var.to(DEV), nbt,
+                                               act=ops.ACT_SIGMOID, training=False)
+        _close(out_e, torch.sigmoid(bn(lin(x))), 2e-2, "eval mode")
+        assert int(nbt.item()) == 1
+
+
+def test_graph_replay_matches_eager_bf16():
+    b = 32
+    outs = []
+    for mode in ("eager", "graph"):
+        mm = _mm(13).to(DEV)
+        tr = MmganTrainer(mm, lr=0.01, compute_dtype="bf16")
+        d = synthetic.mmgan_inputs(b, 50, seed=77, device=DEV)
+        args = (d["piano_roll"], d["durations"], d["beats"], d["noise1"], d["noise2"], d["fake_a"], d["fake_b"])
+        if mode == "graph":
+            tr.capture(*args, d["g1_in_a"], d["g1_in_b"])      # 2 warm-up iterations inside
+            for _ in range(3):
+                dl, gl = tr.replay()
+        else:
+            for _ in range(5):
+                dl, gl = tr.step(*args, g1_in_a=d["g1_in_a"], g1_in_b=d["g1_in_b"])
+        torch.cuda.synchronize()
+        outs.append((dl.item(), gl.item(), mm.discriminator.fc.weight.detach().clone(),
+                     int(mm.generator1.gen[0][1].num_batches_tracked.item())))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
+    assert outs[0][3] == outs[1][3] == 10
+
+
 def test_bf16_trainer_tracks_fp32_losses():
     b = 16
     losses = {}
