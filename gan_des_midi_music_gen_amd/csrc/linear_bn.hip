@@ -37,21 +37,54 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < K; k0 += LB_KT) {
-    // stage x (256 x 32) and W (32 x 32), fp32 -> bf16; lanes run along k (both operands are k-contiguous)
+  // Staging: 16-byte loads (K % 4 == 0 and 16-byte aligned rows, else a scalar path), all loads of a k-tile in flight
+  // together and one k-tile ahead of the MFMAs (register prefetch): these layers are latency-bound, not bandwidth-bound.
+  const bool vec = (K % 4 == 0) && ((((uintptr_t)x | (uintptr_t)w) & 15) == 0);
+  f32x4 ra[8], rb;
+  auto load_tile = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < LB_M * LB_KT / 256; ++i) {
-      const int idx = t + 256 * i, m = idx / LB_KT, k = idx % LB_KT;
-      const float v = (m < M && k0 + k < K) ? x[(int64_t)m * K + k0 + k] : 0.f;
-      As[m * LB_LD + k] = (__bf16)v;
+    for (int i = 0; i < 8; ++i) {
+      const int idx = t + 256 * i, m = idx >> 3, k = k0 + (idx & 7) * 4;
+      ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (m < M) {
+        const float* p = x + (int64_t)m * K + k;
+        if (vec && k + 3 < K) ra[i] = *(const f32x4*)p;
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ra[i][e] = (k + e < K) ? p[e] : 0.f;
+      }
     }
+    {
+      const int n = t >> 3, k = k0 + (t & 7) * 4;
+      rb = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (n0 + n < N) {
+        const float* p = w + (int64_t)(n0 + n) * K + k;
+        if (vec && k + 3 < K) rb = *(const f32x4*)p;
+        else
 #pragma unroll
-    for (int i = 0; i < LB_N * LB_KT / 256; ++i) {
-      const int idx = t + 256 * i, n = idx / LB_KT, k = idx % LB_KT;
-      const float v = (n0 + n < N && k0 + k < K) ? w[(int64_t)(n0 + n) * K + k0 + k] : 0.f;
-      Bs[n * LB_LD + k] = (__bf16)v;
+          for (int e = 0; e < 4; ++e) rb[e] = (k + e < K) ? p[e] : 0.f;
+      }
+    }
+  };
+  load_tile(0);
+  for (int k0 = 0; k0 < K; k0 += LB_KT) {
+    __syncthreads();                       // the previous tile's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = t + 256 * i;
+      bf16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (__bf16)ra[i][e];
+      *(bf16x4*)&As[(idx >> 3) * LB_LD + (idx & 7) * 4] = h;
+    }
+    {
+      bf16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (__bf16)rb[e];
+      *(bf16x4*)&Bs[(t >> 3) * LB_LD + (t & 7) * 4] = h;
     }
     __syncthreads();
+    if (k0 + LB_KT < K) load_tile(k0 + LB_KT);
     bf16x8 b[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8*)&Bs[(16 * j + lr) * LB_LD + 8 * lg];
@@ -61,7 +94,6 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restr
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a, b[j], acc[i][j]);
     }
-    __syncthreads();
   }
   // C layout: col = n (16j + lr), row = m (64wv + 16i + 4lg + r).  Add the Linear bias.
   float bn_[2], mean[2], invstd[2];

@@ -267,6 +267,7 @@ class MmganTrainer(_TrainerBase):
         self.last_g1 = self.last_g2 = None
         self._pack = None          # packed weight images of the fused discriminator kernel (persistent buffer)
         self._graph = None
+        self._gen_stream = None
 
     def invalidate_weights(self):
         self._pack = None
@@ -303,10 +304,18 @@ class MmganTrainer(_TrainerBase):
         t = piano_roll.shape[2]
         dev = piano_roll.device
         fused = self._fused_ok(t)
+        # the generators only feed the (external) bridge: they run on a side stream beside the discriminator kernels
+        main = torch.cuda.current_stream()
+        if self._gen_stream is None:
+            self._gen_stream = torch.cuda.Stream(dev)
+        side = self._gen_stream
         # --- D step (network_tests.py:293-308)
-        g1, g2 = self._generators_forward(noise1, noise2, beats, g1_in_a)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            g1, g2 = self._generators_forward(noise1, noise2, beats, g1_in_a)
         self.last_g1, self.last_g2 = g1, g2
         if callable(fake_a):
+            main.wait_stream(side)
             fake_a = fake_a(g1, g2)
         if fused:
             if self._pack is None:
@@ -332,8 +341,10 @@ class MmganTrainer(_TrainerBase):
         if fused:
             ops.dcnn_pack(w1, b1, w2, b2, wf, bf, t, out=self._pack)     # weights changed: refresh in place
         # --- "G" step (311-315): both generators run again (2nd BN statistics update), D forward on the new fake
-        g1b, g2b = self._generators_forward(noise1, noise2, beats, g1_in_b)
+        with torch.cuda.stream(side):
+            g1b, g2b = self._generators_forward(noise1, noise2, beats, g1_in_b)
         if callable(fake_b):
+            main.wait_stream(side)
             fake_b = fake_b(g1b, g2b)
         if fused:
             if self.elide:
@@ -350,6 +361,7 @@ class MmganTrainer(_TrainerBase):
             else:
                 _, dlg = ops.bce_with_logits(logits_g.view(-1), 1.0, loss_out=self.loss_g)
                 Fn.dcnn_backward(saved_g, dlg, w2, wf, dt)     # dead values (only D's .grad in the reference)
+        main.wait_stream(side)
         self.iterations += 1
         return self.loss_d, self.loss_g
 
