@@ -16,20 +16,27 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Initialise torch.distributed from torchrun's environment; returns (rank, world, local_rank)."""
+    """Initialise torch.distributed from torchrun's environment; returns (rank, world, device_index).
+
+    Rehearsal switches (a one-GPU box cannot run RCCL with two ranks): GDM_DIST_BACKEND=gloo selects the gloo backend
+    (it moves device tensors through the host), GDM_SINGLE_DEVICE=1 places every rank on device 0.
+    """
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1:
         return 0, 1, 0
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    backend = os.environ.get("GDM_DIST_BACKEND", backend)
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
+    dev = 0 if os.environ.get("GDM_SINGLE_DEVICE") == "1" else local
+    if torch.cuda.is_available():
+        torch.cuda.set_device(dev)
     if backend == "nccl":
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        dist.init_process_group(backend, device_id=torch.device("cuda", dev))
     else:
         dist.init_process_group(backend)
-    return dist.get_rank(), dist.get_world_size(), local
+    return dist.get_rank(), dist.get_world_size(), dev
 
 
 def world_size(group=None):
@@ -53,3 +60,12 @@ def allreduce_bucket_(bucket, n_reduce, group=None):
     if w > 1:
         dist.all_reduce(bucket[:n_reduce], op=dist.ReduceOp.SUM, group=group)
     return 1.0 / w
+
+
+def allreduce_async_(tensor, group=None):
+    """Start an in-place SUM all-reduce of a contiguous tensor; returns the work handle (None on a single rank).
+    The collective is ordered after the work already enqueued on the current stream; ``handle.wait()`` makes the
+    then-current stream wait for it."""
+    if world_size(group) <= 1:
+        return None
+    return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=True)

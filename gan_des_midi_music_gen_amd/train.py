@@ -22,7 +22,16 @@ from . import ops
 
 
 class FlatBuffers:
-    """Re-home a list of fp32 parameters into one flat buffer (+ flat grad, exp_avg, exp_avg_sq, `extra` tail floats)."""
+    """Re-home a list of fp32 parameters into one flat buffer with parallel gradient / Adam-moment buffers.
+
+    Physical layout of the gradient bucket (what the data-parallel exchange sees):
+
+        [ extra scalars (loss slots) | gradients of the small parameters | gradient of the largest parameter ]
+
+    so that the exchange can be split in two contiguous collectives: the big tail (model 1: fc1.weight, 99.9 % of the
+    bytes) as soon as its gradient exists -- overlapped with the convolution backward -- and the small head (+ the loss
+    scalar) at the end.  ``views`` / ``grad_views`` keep the caller's parameter order.
+    """
 
     def __init__(self, params, extra=0):
         params = [p for p in params]
@@ -30,15 +39,20 @@ class FlatBuffers:
         dev = params[0].device     # the buffers can be laid out anywhere; the fused step itself needs a HIP device
         self.params = params
         self.numel = sum(p.numel() for p in params)
+        big = max(range(len(params)), key=lambda i: params[i].numel())
+        order = [i for i in range(len(params)) if i != big] + [big]
+        self.n_small = self.numel - params[big].numel()
+        self.n_extra = extra
         self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
-        self.bucket = torch.zeros(self.numel + extra, dtype=torch.float32, device=dev)   # grads | extra scalars
-        self.grad = self.bucket[: self.numel]
-        self.extra = self.bucket[self.numel:]
+        self.bucket = torch.zeros(extra + self.numel, dtype=torch.float32, device=dev)   # extra | small | big
+        self.extra = self.bucket[:extra]
+        self.grad = self.bucket[extra:]
         self.exp_avg = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        self.views, self.grad_views = [], []
+        self.views, self.grad_views = [None] * len(params), [None] * len(params)
         off = 0
-        for p in params:
+        for i in order:
+            p = params[i]
             assert p.dtype == torch.float32 and p.device == dev
             n = p.numel()
             v = self.flat[off:off + n].view(p.shape)
@@ -46,12 +60,20 @@ class FlatBuffers:
             p.data = v
             g = self.grad[off:off + n].view(p.shape)
             p.grad = g
-            self.views.append(v)
-            self.grad_views.append(g)
+            self.views[i] = v
+            self.grad_views[i] = g
             off += n
         self.step_count = 0
         self._hyper = None
         self._hyper_host = None
+
+    # the two contiguous pieces of the data-parallel exchange
+    def bucket_big(self):
+        return self.bucket[self.n_extra + self.n_small:]
+
+    def bucket_head(self, n_scalars=1):
+        """[loss slots | small gradients]; only the first ``n_scalars`` loss slots are meaningful across ranks."""
+        return self.bucket[: self.n_extra + self.n_small]
 
     def adam(self, lr, betas, eps, grad_scale=1.0):
         """One fused Adam launch over the flat buffer.  Step counter and hyper-parameters live in an 8-float device
@@ -81,10 +103,20 @@ class _TrainerBase:
         self.loss_g = self.d.extra[1:2]
         self.iterations = 0
 
+    def _reduce_big_async(self):
+        """Start the SUM all-reduce of the largest gradient (call on the stream that produced it); no-op on 1 rank."""
+        self._pending = dp.allreduce_async_(self.d.bucket_big(), self.pg)
+
     def _reduce_and_step(self):
-        # one flat bucket: every D gradient + the local disc_loss mean; SUM here, 1/world folded into Adam
-        scale = dp.allreduce_bucket_(self.d.bucket, self.d.numel + 1, self.pg)
-        self.d.adam(self.lr, self.betas, self.eps, grad_scale=scale)
+        # head of the bucket = [disc_loss | small gradients]: SUM here, 1/world folded into Adam (and the loss read-out)
+        pending = getattr(self, "_pending", None)
+        if pending is None:
+            dp.allreduce_bucket_(self.d.bucket, self.d.bucket.numel(), self.pg)     # everything in one collective
+        else:
+            dp.allreduce_bucket_(self.d.bucket_head(), self.d.bucket_head().numel(), self.pg)
+            pending.wait()                                                          # current stream waits for the tail
+            self._pending = None
+        self.d.adam(self.lr, self.betas, self.eps, grad_scale=1.0 / self.world)
 
     def disc_loss_value(self):
         return self.loss_d.item() / self.world
@@ -146,6 +178,9 @@ class SimnnTrainer(_TrainerBase):
             dwf1p = ops.gemm(dh.t(), flat, compute=dt)
             ops.permute_pc(dwf1p, n, k // 32, 32, out=outs[4])
             keep.append(dwf1p)
+            if self.world > 1 and outs is self.d.grad_views:
+                # 99.9 % of the exchange (fc1.weight's gradient) starts now and overlaps the convolution backward
+                self._reduce_big_async()
         # main: fc1 data gradient = pooled gradient of the conv trunk
         dflat = ops.gemm(dh, wf1p, compute=dt, out_dtype=dt)
         h1s, w1s = p1.shape[1], p1.shape[2]

@@ -50,10 +50,15 @@ def _worker(rank, world, port, out_dir):
     for gv, g in zip(fb.grad_views, grads):
         gv.copy_(g)
     fb.extra[0] = loss
-    scale = dp.allreduce_bucket_(fb.bucket, fb.numel + 1)
+    # the exchange as the trainers do it: the big tail (fc1.weight) asynchronously first, then [loss | small grads]
+    pending = dp.allreduce_async_(fb.bucket_big())
+    scale = dp.allreduce_bucket_(fb.bucket_head(), fb.bucket_head().numel())
+    pending.wait()
     assert scale == 1.0 / world
     if rank == 0:
-        torch.save({"bucket": fb.bucket.clone() * scale, "numel": fb.numel}, os.path.join(out_dir, "dp.pt"))
+        grads = torch.cat([g.reshape(-1) for g in fb.grad_views]) * scale      # caller's parameter order
+        torch.save({"grads": grads, "loss": fb.extra[0].item() * scale, "numel": fb.numel},
+                   os.path.join(out_dir, "dp.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,10 +72,9 @@ def test_two_rank_bucket_allreduce_equals_single_process(tmp_path):
     real, fake, _ = synthetic.simnn_inputs(GLOBAL_B, HW, seed=42)
     loss, grads = _local_grads(disc, real, fake)
     flat = torch.cat([g.reshape(-1) for g in grads])
-    n = got["numel"]
-    assert n == flat.numel()
-    torch.testing.assert_close(got["bucket"][:n], flat, rtol=1e-5, atol=1e-7)
-    assert abs(got["bucket"][n].item() - loss.item()) < 1e-6
+    assert got["numel"] == flat.numel()
+    torch.testing.assert_close(got["grads"], flat, rtol=1e-5, atol=1e-7)
+    assert abs(got["loss"] - loss.item()) < 1e-6
 
 
 def test_flat_buffers_views_alias_parameters_and_grads():
@@ -79,11 +83,17 @@ def test_flat_buffers_views_alias_parameters_and_grads():
     before = [p.detach().clone() for p in disc.parameters()]
     fb = FlatBuffers(list(disc.parameters()), extra=4)
     assert fb.numel == sum(p.numel() for p in disc.parameters()) and fb.bucket.numel() == fb.numel + 4
+    params = list(disc.parameters())
+    big = max(range(len(params)), key=lambda i: params[i].numel())
     off = 0
-    for p, b0 in zip(disc.parameters(), before):
-        assert torch.equal(p.detach(), b0)
+    for i in [j for j in range(len(params)) if j != big] + [big]:        # physical order: small ..., largest last
+        p = params[i]
+        assert torch.equal(p.detach(), before[i])
         assert p.data_ptr() == fb.flat.data_ptr() + 4 * off and p.grad.data_ptr() == fb.grad.data_ptr() + 4 * off
+        assert fb.views[i].data_ptr() == p.data_ptr() and fb.grad_views[i].data_ptr() == p.grad.data_ptr()
         off += p.numel()
+    assert fb.bucket_big().numel() == params[big].numel() and fb.bucket_big().data_ptr() == params[big].grad.data_ptr()
+    assert fb.bucket_head().data_ptr() == fb.bucket.data_ptr() and fb.extra.data_ptr() == fb.bucket.data_ptr()
     with pytest.raises(Exception):
         fb.adam(1e-3, (0.9, 0.999), 1e-8)      # the optimizer step is HIP-only: no CPU fallback
 

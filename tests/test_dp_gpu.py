@@ -1,0 +1,87 @@
+"""GPU, 2 ranks on ONE device over gloo (RCCL refuses two ranks on one GPU): the data-parallel trainer path end to end
+-- per-rank shards, early asynchronous all-reduce of fc1's gradient, head all-reduce, 1/world in Adam -- must
+reproduce the single-process iteration on the global batch (fp32 mode: parameters to ~1e-6, losses to 1e-5)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["GDM_ROOT"])
+from gan_des_midi_music_gen_amd import SIMNN, dp, synthetic, network_tests as NT
+from gan_des_midi_music_gen_amd.train import SimnnTrainer, MmganTrainer
+rank, world, devi = dp.init_from_env()
+dev = torch.device("cuda", devi)
+GB, hw = 4, (32, 40)
+torch.manual_seed(0)
+gen = SIMNN.Generator().apply(SIMNN.weights_init).to(dev)
+disc = SIMNN.Discriminator(input_hw=hw).apply(SIMNN.weights_init).to(dev)
+tr = SimnnTrainer(gen, disc, compute_dtype="fp32")
+lo, hi = dp.shard_bounds(GB, world, rank)
+out = {}
+for it in range(3):
+    real, fake, noise = synthetic.simnn_inputs(GB, hw, seed=900 + it, device=dev)
+    dl, gl = tr.step(real[lo:hi].contiguous(), noise[lo:hi].contiguous(), fake[lo:hi].contiguous())
+torch.cuda.synchronize()
+out["simnn"] = {"d_loss": tr.disc_loss_value(), "fc1": disc.fc1.weight.detach().cpu(), "c1": disc.conv1.weight.detach().cpu(),
+                "fc2b": disc.fc2.bias.detach().cpu()}
+torch.manual_seed(0)
+mm = NT.MultiModalGAN(z_dim=50, adj_size=(64, 64), roll_size=(2, 128, 50), input_dim=50, output_dim=20, device=dev)
+mt = MmganTrainer(mm, compute_dtype="fp32")
+for it in range(2):
+    d = synthetic.mmgan_inputs(GB, 50, seed=950 + it, device=dev)
+    sl = slice(lo, hi)
+    mt.step(d["piano_roll"][sl].contiguous(), d["durations"][sl].contiguous(), d["beats"][sl].contiguous(),
+            d["noise1"][sl].contiguous(), d["noise2"][sl].contiguous(), d["fake_a"][sl].contiguous(),
+            d["fake_b"][sl].contiguous(), g1_in_a=d["g1_in_a"][sl].contiguous(), g1_in_b=d["g1_in_b"][sl].contiguous())
+torch.cuda.synchronize()
+out["mmgan"] = {"d_loss": mt.disc_loss_value(), "fc": mm.discriminator.fc.weight.detach().cpu(),
+                "c2": mm.discriminator.conv2.weight.detach().cpu()}
+if rank == 0:
+    torch.save(out, os.environ["GDM_OUT"])
+if world > 1:
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+'''
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(world, out_path, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, GDM_ROOT=ROOT, GDM_OUT=str(out_path), GDM_DIST_BACKEND="gloo", GDM_SINGLE_DEVICE="1",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world))
+    procs = []
+    for r in range(world):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out[-3000:]
+
+
+def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path):
+    _run(1, tmp_path / "one.pt", tmp_path)
+    _run(2, tmp_path / "two.pt", tmp_path)
+    one = torch.load(tmp_path / "one.pt", weights_only=True)
+    two = torch.load(tmp_path / "two.pt", weights_only=True)
+    for model in ("simnn", "mmgan"):
+        a, b = one[model], two[model]
+        assert abs(a["d_loss"] - b["d_loss"]) < 1e-5 * max(1.0, abs(a["d_loss"])), (model, a["d_loss"], b["d_loss"])
+        for k in a:
+            if k != "d_loss":
+                # Adam's first steps move every weight by ~lr regardless of |g|: allow a few 1e-6 of drift
+                assert (a[k] - b[k]).abs().max().item() < 3e-5, (model, k, (a[k] - b[k]).abs().max().item())
