@@ -16,6 +16,43 @@
 
 namespace {
 
+// Diagnostic build only (-DGDM_STAMPS, tools/stamps.py): per-workgroup cycle totals of the phases of a persistent
+// kernel's tile loop, taken with s_memtime by every wave and written by wave 0 to a buffer nothing else reads.
+#ifdef GDM_STAMPS
+__device__ unsigned long long gdm_stamp_buf[1024 * 8];
+struct Stamps {
+  uint64_t last, ph[8];
+  __device__ __forceinline__ void start() {
+    for (int k = 0; k < 8; ++k) ph[k] = 0;
+    __builtin_amdgcn_sched_barrier(0);
+    last = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void mark(int k) {
+    __builtin_amdgcn_sched_barrier(0);
+    const uint64_t now = __builtin_amdgcn_s_memtime();
+    ph[k] += now - last;
+    last = now;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void flush() {
+    if (threadIdx.x == 0)
+      for (int k = 0; k < 8; ++k) gdm_stamp_buf[(blockIdx.x & 1023) * 8 + k] = ph[k];
+  }
+};
+#define STAMP_DECL Stamps stamps_; stamps_.start()
+#define STAMP(k) stamps_.mark(k)
+#define STAMP_FLUSH stamps_.flush()
+#define STAMP_ARG , Stamps& stamps_
+#define STAMP_PASS , stamps_
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH
+#define STAMP_ARG
+#define STAMP_PASS
+#endif
+
 constexpr int COLS = 64;   // conv-output columns handled per workgroup (column super-tile)
 
 template <typename T> struct Px;  // LDS pixel-record strides (elements) for 16- and 32-channel records
@@ -254,6 +291,42 @@ __device__ __forceinline__ void copy_to_lds(T* __restrict__ dst, const T* __rest
   for (int i = threadIdx.x; i < chunks; i += 256) ((f32x4*)dst)[i] = ((const f32x4*)src)[i];
 }
 
+// Tile staging goes through buffer descriptors: a lane that falls outside the image hands the load an offset past
+// num_records and the hardware returns zeros (stores are dropped), so halo handling needs no branch and no select.
+// Branch-free staging matters twice: the loads of a tile issue back to back, and hipcc's s_waitcnt bookkeeping stays
+// exact (with loads inside exec-masked branches it drained the whole queue -- vmcnt(0) -- right after issuing a
+// prefetch, which turned "prefetch" into "wait").  All tensors addressed this way are < 2 GiB (checked on the host).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr uint32_t BUF_OOB = 0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  // descriptor words must be provably wave-uniform, or every buffer op gets wrapped in a waterfall loop
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0,
+                                           __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 buf_load16(rsrc_t r, uint32_t off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ uint64_t buf_load8(rsrc_t r, uint32_t off) {
+  return __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+}
+__device__ __forceinline__ float buf_load4(rsrc_t r, uint32_t off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void buf_store16(rsrc_t r, uint32_t off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+__device__ __forceinline__ void buf_store8(rsrc_t r, uint32_t off, uint64_t v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0, 0);
+}
+__device__ __forceinline__ void buf_store4(rsrc_t r, uint32_t off, uint32_t v) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, r, off, 0, 0);
+}
+
 // p1 halo band (rows r_first .. r_first+NR-1, cols c_first .. c_first+WP-1) -> LDS [row][col][S16], zero outside.
 // Two phases so that every global load of the tile is in flight before the first LDS store.
 template <typename T, int NR> struct P1Stage {
@@ -263,22 +336,25 @@ template <typename T, int NR> struct P1Stage {
 };
 
 template <typename T, int NR>
-__device__ __forceinline__ void p1_band_load(P1Stage<T, NR>& st, const T* __restrict__ p1b, int H1, int W1,
+__device__ __forceinline__ void p1_band_load(P1Stage<T, NR>& st, rsrc_t p1r, uint32_t img_off, int H1, int W1,
                                              int r_first, int c_first) {
-  constexpr int WP = C2<T>::WP, PIECES = P1Stage<T, NR>::PIECES, EPP = 16 / PIECES;
+  constexpr int WP = C2<T>::WP, PIECES = P1Stage<T, NR>::PIECES;
 #pragma unroll
   for (int k = 0; k < P1Stage<T, NR>::ITERS; ++k) {
     const int i = threadIdx.x + 256 * k;
     const int piece = i % PIECES, pix = i / PIECES;
     const int cl = pix % WP, rl = pix / WP;
     const int r = r_first + rl, c = c_first + cl;
-    st.v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (i < NR * WP * PIECES && r >= 0 && r < H1 && c >= 0 && c < W1)
-      st.v[k] = *(const f32x4*)(p1b + ((int64_t)r * W1 + c) * 16 + piece * EPP);
+    const bool ok = i < NR * WP * PIECES && r >= 0 && r < H1 && c >= 0 && c < W1;
+    const uint32_t off = img_off + (uint32_t)(r * W1 + c) * (16 * sizeof(T)) + piece * 16;   // bytes
+    st.v[k] = buf_load16(p1r, ok ? off : BUF_OOB);
   }
 }
 
-template <typename T, int NR>
+// SPLIT: records of a band row are stored even columns first, then odd columns ([row][parity][WP/2][S16]), so that a
+// reader whose lanes walk every second column (conv2 forward: a lane owns one pooled column) still steps one record
+// per lane -- the conflict-free pattern of the plain layout.
+template <typename T, int NR, bool SPLIT = false>
 __device__ __forceinline__ void p1_band_store(const P1Stage<T, NR>& st, T* __restrict__ in_s) {
   constexpr int S16 = C2<T>::S16, WP = C2<T>::WP, PIECES = P1Stage<T, NR>::PIECES, EPP = 16 / PIECES;
 #pragma unroll
@@ -286,7 +362,12 @@ __device__ __forceinline__ void p1_band_store(const P1Stage<T, NR>& st, T* __res
     const int i = threadIdx.x + 256 * k;
     if (i >= NR * WP * PIECES) continue;
     const int piece = i % PIECES, pix = i / PIECES;
-    T* dst = in_s + pix * S16 + piece * EPP;
+    int rec = pix;
+    if constexpr (SPLIT) {
+      const int cl = pix % WP, rl = pix / WP;
+      rec = (rl * 2 + (cl & 1)) * (WP / 2) + (cl >> 1);
+    }
+    T* dst = in_s + rec * S16 + piece * EPP;
     if constexpr (sizeof(T) == 2) *(f32x4*)dst = st.v[k];
     else { dst[0] = st.v[k][0]; dst[1] = st.v[k][1]; dst[2] = st.v[k][2]; dst[3] = st.v[k][3]; }
   }
@@ -307,9 +388,9 @@ template <typename T, int NR, int NC, bool HALO> struct DcStage {
 };
 
 template <typename T, int NR, int NC, bool HALO>
-__device__ __forceinline__ void dc2_load(DcStage<T, NR, NC, HALO>& st, const T* __restrict__ dp2b,
-                                         const uint8_t* __restrict__ code2b, int H2, int W2, int r_first,
-                                         int c_first) {
+__device__ __forceinline__ void dc2_load(DcStage<T, NR, NC, HALO>& st, rsrc_t dp2r, rsrc_t code2r, uint32_t img_off,
+                                         int H2, int W2, int r_first, int c_first) {
+  // img_off = element (= code byte) offset of the image; out-of-image items read zeros: gradient 0 under code 0
   using S = DcStage<T, NR, NC, HALO>;
   const int t = threadIdx.x, og = t & 3;
   const int pr_first = r_first >> 1, pc_first = c_first >> 1;           // arithmetic shift = floor
@@ -317,15 +398,11 @@ __device__ __forceinline__ void dc2_load(DcStage<T, NR, NC, HALO>& st, const T* 
   for (int k = 0; k < S::ITERS; ++k) {
     const int it = (t >> 2) + 64 * k;
     const int pr = pr_first + it / S::NPC, pc = pc_first + it % S::NPC;
-    st.cd[k] = 0x0404040404040404ull;
-#pragma unroll
-    for (int q = 0; q < (int)(sizeof(T) == 2 ? 1 : 2); ++q) st.g[k][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (it < S::NPR * S::NPC && pr >= 0 && pr < H2 && pc >= 0 && pc < W2) {
-      const int64_t gi = (((int64_t)pr * W2 + pc) * 32) + 8 * og;
-      st.cd[k] = *(const uint64_t*)(code2b + gi);
-      st.g[k][0] = *(const f32x4*)(dp2b + gi);
-      if constexpr (sizeof(T) == 4) st.g[k][1] = *(const f32x4*)(dp2b + gi + 4);
-    }
+    const bool ok = it < S::NPR * S::NPC && pr >= 0 && pr < H2 && pc >= 0 && pc < W2;
+    const uint32_t gi = img_off + (uint32_t)(pr * W2 + pc) * 32 + 8 * og;
+    st.cd[k] = buf_load8(code2r, ok ? gi : BUF_OOB);
+    st.g[k][0] = buf_load16(dp2r, ok ? gi * (uint32_t)sizeof(T) : BUF_OOB);
+    if constexpr (sizeof(T) == 4) st.g[k][1] = buf_load16(dp2r, ok ? gi * 4u + 16u : BUF_OOB);
   }
 }
 
@@ -375,103 +452,170 @@ __device__ __forceinline__ void dc2_expand(const DcStage<T, NR, NC, HALO>& st, i
 }
 
 // ---------------------------------------------------------------------------------------------------- conv2 forward
+// One tile (4 conv rows x 64 columns of image b) from the LDS band in_s: MFMA implicit GEMM + bias/ReLU/pool epilogue.
+// Wave (rp, half) computes conv rows 2rp, 2rp+1 x 32 columns x 32 channels.  The mapping is chosen so that the 2x2
+// pooling window never leaves a lane: column tile j holds the band columns 32*half + 2*lr + j (lane lr = pooled column),
+// so {acc[i][d][j]} over (d, j) ARE the window; and accumulator row 4*lg + r of channel tile i is channel 8*lg + 4*i + r,
+// so a lane ends up with 8 consecutive channels of one pooled pixel = one 16-byte store (+ one 8-byte code store).
+// The bias is the accumulator's initial value.
 template <typename T>
-__global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1, const T* __restrict__ wf,
-                                                        const float* __restrict__ bias, int H1, int W1, int H2,
-                                                        int W2, T* __restrict__ p2, uint8_t* __restrict__ code2) {
-  constexpr int S16 = C2<T>::S16, KP = C2<T>::KPF, WP = C2<T>::WP;
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-  T* in_s = (T*)dyn_smem;
-  T* w_s = in_s + C2<T>::IN_ELEMS;
+__device__ __forceinline__ void conv2_fwd_tile(const T* __restrict__ in_s, const T* __restrict__ w_s,
+                                               const float (&bo)[2][4], int b, int rq, int c0, int H2, int W2,
+                                               rsrc_t p2r, rsrc_t code2r STAMP_ARG) {
+  constexpr int S16 = C2<T>::S16, KP = C2<T>::KPF, HP = C2<T>::WP / 2;
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
-  const int c0 = blockIdx.x * COLS, rq = blockIdx.y, b = blockIdx.z;
   const int rp = wv >> 1, half = wv & 1;            // wave -> (pooled row of the tile, 32-column half)
-  P1Stage<T, ROWS + 2> st;
-  p1_band_load(st, p1 + (int64_t)b * H1 * W1 * 16, H1, W1, ROWS * rq - 1, c0 - 1);
-  copy_to_lds(w_s, wf, C2<T>::WF_ELEMS);
-  p1_band_store(st, in_s);
-  __syncthreads();
-
-  f32x4 acc[2][2][2];                               // [m-tile][row of the pair][column tile]
+  f32x4 acc[2][2][2];                               // [channel tile][row of the pair][column parity]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][d][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int colb = 32 * half + lr;
+      for (int j = 0; j < 2; ++j) acc[i][d][j] = (f32x4){bo[i][0], bo[i][1], bo[i][2], bo[i][3]};
+  const int arow = 8 * (lr >> 2) + (lr & 3);        // + 4*i: the channel this lane's A row stands for
+  const int pcol = 16 * half + lr;                  // pooled column within the tile
   if constexpr (sizeof(T) == 2) {
-#pragma unroll
-    for (int ks = 0; ks < 5; ++ks) {
+    // fragments of k-step ks+1 are read from LDS before the 8 MFMAs of k-step ks are issued (register double buffer),
+    // so that the LDS latency sits under the matrix pipe instead of in front of every MFMA pair
+    bf16x8 a[2][2], bb[2][2][2];
+    auto frags = [&](int ks, bf16x8 (&aa)[2], bf16x8 (&bx)[2][2]) {
       int tap = 2 * ks + (lg >> 1);
       tap = tap > 8 ? 8 : tap;               // k >= 144: weights are zero, read any valid record
       const int kh = tap / 3, kw = tap % 3;
-      bf16x8 a[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8*)&w_s[(16 * i + lr) * KP + 32 * ks + 8 * lg];
+      for (int i = 0; i < 2; ++i) aa[i] = *(const bf16x8*)&w_s[(arow + 4 * i) * KP + 32 * ks + 8 * lg];
 #pragma unroll
       for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const bf16x8 bb = *(const bf16x8*)&in_s[((2 * rp + d + kh) * WP + colb + 16 * j + kw) * S16 + 8 * (lg & 1)];
-#pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i][d][j] = mfma16(a[i], bb, acc[i][d][j]);
+          const int q = j + kw;               // band column 2*pcol + q
+          bx[d][j] = *(const bf16x8*)&in_s[(((2 * rp + d + kh) * 2 + (q & 1)) * HP + pcol + (q >> 1)) * S16 +
+                                           8 * (lg & 1)];
         }
+    };
+    frags(0, a[0], bb[0]);
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      if (ks + 1 < 5) frags(ks + 1, a[(ks + 1) & 1], bb[(ks + 1) & 1]);
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][d][j] = mfma16(a[ks & 1][i], bb[ks & 1][d][j], acc[i][d][j]);
     }
   } else {
 #pragma unroll 2
     for (int ks = 0; ks < 36; ++ks) {
       const int tap = ks >> 2, ci = 4 * (ks & 3) + lg;
       const int kh = tap / 3, kw = tap % 3;
-      float a[2];
+      float a[2], bb[2][2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = w_s[(16 * i + lr) * KP + 4 * ks + lg];
+      for (int i = 0; i < 2; ++i) a[i] = w_s[(arow + 4 * i) * KP + 4 * ks + lg];
 #pragma unroll
       for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const float bb = in_s[((2 * rp + d + kh) * WP + colb + 16 * j + kw) * S16 + ci];
-#pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i][d][j] = mfma16(a[i], bb, acc[i][d][j]);
+          const int q = j + kw;
+          bb[d][j] = in_s[(((2 * rp + d + kh) * 2 + (q & 1)) * HP + pcol + (q >> 1)) * S16 + ci];
         }
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][d][j] = mfma16(a[i], bb[d][j], acc[i][d][j]);
     }
   }
-  // ---- epilogue on the accumulator tile: bias, ReLU, 2x2 max-pool + code; C layout: col (lr) = pixel,
-  //      row (4*lg + r) = channel within m-tile i  ->  an even lane owns 4 consecutive channels of one pooled pixel
+  STAMP(2);
+  // ---- epilogue, all in-lane: first maximum of the window in scan order (as aten::max_pool2d_with_indices), ReLU,
+  //      code = window position, or 4 when the pooled value is not positive (ReLU passes no gradient)
+  float best[8];
+  uint64_t codes = 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      float best[4];
-      uint32_t codes = 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float bo = bias[16 * i + 4 * lg + r];
-        float v0 = acc[i][0][j][r] + bo, v1 = acc[i][1][j][r] + bo;
-        v0 = v0 > 0.f ? v0 : 0.f;
-        v1 = v1 > 0.f ? v1 : 0.f;
-        const float u0 = __shfl_xor(v0, 1, 64), u1 = __shfl_xor(v1, 1, 64);
-        float bv = v0; uint32_t bi = 0;
-        if (u0 > bv) { bv = u0; bi = 1; }
-        if (v1 > bv) { bv = v1; bi = 2; }
-        if (u1 > bv) { bv = u1; bi = 3; }
-        best[r] = bv;
-        codes |= (bv > 0.f ? bi : 4u) << (8 * r);
-      }
-      const int ph = (ROWS / 2) * rq + rp, pw = (c0 + colb + 16 * j) >> 1;
-      if ((lr & 1) == 0 && ph < H2 && pw < W2) {
-        const int64_t gi = ((((int64_t)b * H2 + ph) * W2 + pw) * 32) + 16 * i + 4 * lg;
-        if constexpr (sizeof(T) == 2) {
-          bf16x4 h;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) h[r] = (__bf16)best[r];
-          *(bf16x4*)(p2 + gi) = h;
-        } else {
-          *(f32x4*)(p2 + gi) = (f32x4){best[0], best[1], best[2], best[3]};
-        }
-        *(uint32_t*)(code2 + gi) = codes;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float v0 = acc[i][0][0][r], v1 = acc[i][0][1][r], v2 = acc[i][1][0][r], v3 = acc[i][1][1][r];
+      const float m = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+      uint32_t pos = 3u;                      // select chain, last write wins = first maximum (no branches)
+      pos = v2 == m ? 2u : pos;
+      pos = v1 == m ? 1u : pos;
+      pos = v0 == m ? 0u : pos;
+      best[4 * i + r] = fmaxf(m, 0.f);
+      codes |= (uint64_t)(m > 0.f ? pos : 4u) << (8 * (4 * i + r));
     }
+  const int ph = (ROWS / 2) * rq + rp, pw = (c0 >> 1) + pcol;
+  const bool ok = ph < H2 && pw < W2;
+  const uint32_t gi = (uint32_t)((b * H2 + ph) * W2 + pw) * 32 + 8 * lg;
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 h;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[e] = (__bf16)best[e];
+    buf_store16(p2r, ok ? gi * 2u : BUF_OOB, __builtin_bit_cast(f32x4, h));
+  } else {
+    buf_store16(p2r, ok ? gi * 4u : BUF_OOB, (f32x4){best[0], best[1], best[2], best[3]});
+    buf_store16(p2r, ok ? gi * 4u + 16u : BUF_OOB, (f32x4){best[4], best[5], best[6], best[7]});
+  }
+  buf_store8(code2r, ok ? gi : BUF_OOB, codes);
+}
+
+// Persistent over tiles; the weight image and the biases are fetched once per workgroup; input bands are prefetched
+// TWO tiles ahead in two register sets (a tile's MFMA + epilogue is ~4x shorter than an HBM round trip under load, so
+// one tile of look-ahead leaves the workgroup waiting for memory most of the time).
+template <typename T>
+__global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1, const T* __restrict__ wf,
+                                                        const float* __restrict__ bias, int H1, int W1, int H2,
+                                                        int W2, int n_ctiles, int n_tiles, T* __restrict__ p2,
+                                                        uint8_t* __restrict__ code2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  T* in_s = (T*)dyn_smem;
+  T* w_s = in_s + C2<T>::IN_ELEMS;
+  const int lg = (threadIdx.x & 63) >> 4;
+  const int nrq = (2 * H2 + ROWS - 1) / ROWS, G = gridDim.x;
+  // Every path through the loop issues the SAME number of global loads (tile indices past the end are clamped to the
+  // last tile instead of skipping the loads): the hardware counts memory operations in order, so only then can the
+  // compiler wait for "all but the other register set's loads" (vmcnt(N)) instead of draining the queue (vmcnt(0)).
+  STAMP_DECL;
+  const int B = n_tiles / (n_ctiles * nrq);
+  const rsrc_t p1r = make_rsrc(p1, (uint32_t)B * H1 * W1 * 16 * sizeof(T));
+  const rsrc_t p2r = make_rsrc(p2, (uint32_t)B * H2 * W2 * 32 * sizeof(T));
+  const rsrc_t code2r = make_rsrc(code2, (uint32_t)B * H2 * W2 * 32);
+  auto issue = [&](P1Stage<T, ROWS + 2>& st, int u) {
+    u = min(u, n_tiles - 1);
+    const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq, b = u / (n_ctiles * nrq);
+    p1_band_load(st, p1r, (uint32_t)b * H1 * W1 * 16 * sizeof(T), H1, W1, ROWS * rq - 1, ct * COLS - 1);
+  };
+  auto run = [&](P1Stage<T, ROWS + 2>& st, int u, const float (&bo)[2][4]) {
+    const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq, b = u / (n_ctiles * nrq);
+    p1_band_store<T, ROWS + 2, true>(st, in_s);
+    STAMP(6);
+    __syncthreads();
+    STAMP(0);
+    issue(st, u + 2 * G);                                   // this register set is free again: two tiles ahead
+    STAMP(1);
+    conv2_fwd_tile<T>(in_s, w_s, bo, b, rq, ct * COLS, H2, W2, p2r, code2r STAMP_PASS);
+    STAMP(3);
+    __syncthreads();                                        // the band may be overwritten
+    STAMP(4);
+  };
+  copy_to_lds(w_s, wf, C2<T>::WF_ELEMS);
+  float bo[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bo[i][r] = bias[8 * lg + 4 * i + r];     // channel map of conv2_fwd_tile
+  P1Stage<T, ROWS + 2> sa, sb;
+  int u = blockIdx.x;                                       // host guarantees gridDim.x <= n_tiles
+  issue(sa, u);
+  issue(sb, u + G);
+  STAMP(5);
+  for (; u + G < n_tiles; u += 2 * G) {
+    run(sa, u, bo);
+    run(sb, u + G, bo);
+  }
+  if (u < n_tiles) run(sa, u, bo);
+  STAMP_FLUSH;
 }
 
 // ---------------------------------------------------------------------------------- conv2 backward (data [+ conv1 dW])
@@ -503,31 +647,36 @@ template <typename T, bool FUSE> struct BdTileRegs {
   uint64_t codes[FUSE ? 4 : 1];
 };
 
+template <bool FUSE> struct BdRsrc {
+  rsrc_t dp2, code2, dp1, code1;
+};
+
 template <typename T, bool FUSE>
-__device__ __forceinline__ void bd_issue(BdTileRegs<T, FUSE>& rg, int u, int n_ctiles, int nrq,
-                                         const T* __restrict__ dp2, const uint8_t* __restrict__ code2, int H1, int W1,
-                                         int H2, int W2, const uint64_t* __restrict__ code1,
-                                         const float* __restrict__ x0, const float* __restrict__ x1, int bsplit, int H,
-                                         int W) {
+__device__ __forceinline__ void bd_issue(BdTileRegs<T, FUSE>& rg, int u, int n_ctiles, int nrq, const BdRsrc<FUSE>& rs,
+                                         int H1, int W1, int H2, int W2, const float* __restrict__ x0,
+                                         const float* __restrict__ x1, int bsplit, int H, int W) {
   constexpr int XW = BD_XW;
   const int t = threadIdx.x, lr = t & 15, wv = t >> 6;
   const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq, b = u / (n_ctiles * nrq);
   const int c0 = ct * BD_COLS;
-  dc2_load(rg.dc, dp2 + (int64_t)b * H2 * W2 * 32, code2 + (int64_t)b * H2 * W2 * 32, H2, W2, ROWS * rq - 1, c0 - 1);
+  dc2_load(rg.dc, rs.dp2, rs.code2, (uint32_t)b * H2 * W2 * 32, H2, W2, ROWS * rq - 1, c0 - 1);
   if constexpr (FUSE) {
+    // the input image of sample b lives in one of two tensors (real | generated): one descriptor per tile
     const float* xb = (b < bsplit) ? x0 + (int64_t)b * H * W : x1 + (int64_t)(b - bsplit) * H * W;
+    const rsrc_t xr_ = make_rsrc(xb, (uint32_t)H * W * 4);
 #pragma unroll
     for (int k = 0; k < BdTileRegs<T, FUSE>::XIT; ++k) {
       const int i = t + 256 * k;
       const int bc = i % XW, br = i / XW;
       const int xr = 2 * ROWS * rq - 1 + br, xc = 2 * c0 - 1 + bc;
-      rg.xv[k] = (i < XROWS * XW && xr >= 0 && xr < H && xc >= 0 && xc < W) ? xb[(int64_t)xr * W + xc] : 0.f;
+      const bool ok = i < XROWS * XW && xr >= 0 && xr < H && xc >= 0 && xc < W;
+      rg.xv[k] = buf_load4(xr_, ok ? (uint32_t)(xr * W + xc) * 4u : BUF_OOB);
     }
     const int ih = ROWS * rq + wv;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int iw = c0 + 16 * j + lr;
-      rg.codes[j] = (ih < H1 && iw < W1) ? code1[((int64_t)b * H1 + ih) * W1 + iw] : 0ull;
+      rg.codes[j] = buf_load8(rs.code1, (ih < H1 && iw < W1) ? (uint32_t)((b * H1 + ih) * W1 + iw) * 8u : BUF_OOB);
     }
   }
 }
@@ -559,13 +708,20 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
     for (int q = 0; q < 4; ++q) a1[r][q] = 0.f;
   }
 
-  BdTileRegs<T, FUSE> rg;
-  int u = blockIdx.x;
-  if (BD_PREFETCH && u < n_tiles)
-    bd_issue<T, FUSE>(rg, u, n_ctiles, nrq, dp2, code2, H1, W1, H2, W2, code1, x0, x1, bsplit, H, W);
+  const int B = n_tiles / (n_ctiles * nrq), G = gridDim.x;
+  BdRsrc<FUSE> rs;
+  rs.dp2 = make_rsrc(dp2, (uint32_t)B * H2 * W2 * 32 * sizeof(T));
+  rs.code2 = make_rsrc(code2, (uint32_t)B * H2 * W2 * 32);
+  rs.dp1 = make_rsrc(dp1, dp1 ? (uint32_t)B * H1 * W1 * 16 * sizeof(T) : 0u);
+  rs.code1 = make_rsrc(code1, FUSE ? (uint32_t)B * H1 * W1 * 8 : 0u);
+  STAMP_DECL;
   copy_to_lds(w_s, wb, C2<T>::WB_ELEMS);
-  for (; u < n_tiles; u += gridDim.x) {
-    if (!BD_PREFETCH) bd_issue<T, FUSE>(rg, u, n_ctiles, nrq, dp2, code2, H1, W1, H2, W2, code1, x0, x1, bsplit, H, W);
+  BdTileRegs<T, FUSE> rg;
+  int u = blockIdx.x;                                       // host guarantees gridDim.x <= n_tiles
+  if (BD_PREFETCH) bd_issue<T, FUSE>(rg, u, n_ctiles, nrq, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
+  STAMP(6);
+  for (; u < n_tiles; u += G) {
+    if (!BD_PREFETCH) bd_issue<T, FUSE>(rg, u, n_ctiles, nrq, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
     const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq, b = u / (n_ctiles * nrq);
     const int c0 = ct * BD_COLS;
     const int ih = ROWS * rq + wv;                          // this wave's output row
@@ -581,23 +737,33 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
 #pragma unroll
       for (int j = 0; j < 4; ++j) codes[j] = rg.codes[j];
     }
+    STAMP(7);
     __syncthreads();
-    if (BD_PREFETCH && u + (int)gridDim.x < n_tiles)   // next tile's loads fly during the work below
-      bd_issue<T, FUSE>(rg, u + gridDim.x, n_ctiles, nrq, dp2, code2, H1, W1, H2, W2, code1, x0, x1, bsplit, H, W);
+    STAMP(0);
+    // next tile's loads fly during the work below; issued on EVERY iteration (the last one re-reads its own, cache-hot
+    // tile) so that the loop has no branch around memory operations
+    if (BD_PREFETCH)
+      bd_issue<T, FUSE>(rg, u + G < n_tiles ? u + G : u, n_ctiles, nrq, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
+    STAMP(1);
 
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (sizeof(T) == 2) {
-#pragma unroll
-      for (int ks = 0; ks < 9; ++ks) {           // one (flipped) tap = 32 channels per k-step
+      // one (flipped) tap = 32 channels per k-step; the fragments of k-step ks+1 are read before the MFMAs of ks issue
+      bf16x8 a[2], bb[2][4];
+      auto frags = [&](int ks, bf16x8& aa, bf16x8 (&bx)[4]) {
         const int ah = ks / 3, aw = ks % 3;
-        const bf16x8 a = *(const bf16x8*)&w_s[lr * KP + 32 * ks + 8 * lg];
+        aa = *(const bf16x8*)&w_s[lr * KP + 32 * ks + 8 * lg];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const bf16x8 bb = *(const bf16x8*)&dc_s[((wv + ah) * WP + 16 * j + lr + aw) * S32 + 8 * lg];
-          acc[j] = mfma16(a, bb, acc[j]);
-        }
+        for (int j = 0; j < 4; ++j) bx[j] = *(const bf16x8*)&dc_s[((wv + ah) * WP + 16 * j + lr + aw) * S32 + 8 * lg];
+      };
+      frags(0, a[0], bb[0]);
+#pragma unroll
+      for (int ks = 0; ks < 9; ++ks) {
+        if (ks + 1 < 9) frags(ks + 1, a[(ks + 1) & 1], bb[(ks + 1) & 1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = mfma16(a[ks & 1], bb[ks & 1][j], acc[j]);
       }
     } else {
 #pragma unroll 2
@@ -612,24 +778,25 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
         }
       }
     }
+    STAMP(2);
     // C layout: col (lr) = pixel, row (4*lg + r) = input channel ci
     if (dp1 != nullptr) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int iw = c0 + 16 * j + lr;
-        if (ih < H1 && iw < W1) {
-          T* dst = dp1 + (((int64_t)b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
-          if constexpr (sizeof(T) == 2) {
-            bf16x4 v;
+        const bool ok = ih < H1 && iw < W1;
+        const uint32_t di = (uint32_t)((b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
+        if constexpr (sizeof(T) == 2) {
+          bf16x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[j][r];
-            *(bf16x4*)dst = v;
-          } else {
-            *(f32x4*)dst = acc[j];
-          }
+          for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[j][r];
+          buf_store8(rs.dp1, ok ? di * 2u : BUF_OOB, __builtin_bit_cast(uint64_t, v));
+        } else {
+          buf_store16(rs.dp1, ok ? di * 4u : BUF_OOB, acc[j]);
         }
       }
     }
+    STAMP(3);
     if constexpr (FUSE) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -650,8 +817,11 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
         __builtin_amdgcn_sched_barrier(0);   // keep the 16 LDS gathers of one column tile from piling up across tiles
       }
     }
+    STAMP(4);
     __syncthreads();     // every wave is done with this tile's LDS images
+    STAMP(5);
   }
+  STAMP_FLUSH;
   if constexpr (FUSE) {
     // one reduction per workgroup (not per tile): over the 16 lanes that share a channel group, then over the waves
 #pragma unroll
@@ -704,17 +874,26 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
   for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
   const int nrq = (H1 + ROWS - 1) / ROWS;
 
-  for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
-    const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq, b = u / (n_ctiles * nrq);
+  const rsrc_t dp2r = make_rsrc(dp2, (uint32_t)B * H2 * W2 * 32 * sizeof(T));
+  const rsrc_t code2r = make_rsrc(code2, (uint32_t)B * H2 * W2 * 32);
+  const rsrc_t p1r = make_rsrc(p1, (uint32_t)B * H1 * W1 * 16 * sizeof(T));
+  DcStage<T, ROWS, COLS, false> st;
+  P1Stage<T, ROWS + 2> sp;
+  auto issue = [&](int v) {
+    const int ct = v % n_ctiles, rq = (v / n_ctiles) % nrq, b = v / (n_ctiles * nrq);
+    dc2_load(st, dp2r, code2r, (uint32_t)b * H2 * W2 * 32, H2, W2, ROWS * rq, ct * COLS);
+    p1_band_load(sp, p1r, (uint32_t)b * H1 * W1 * 16 * sizeof(T), H1, W1, ROWS * rq - 1, ct * COLS - 1);
+  };
+  const int G = gridDim.x;
+  int u = blockIdx.x;                                       // host guarantees gridDim.x <= n_units
+  issue(u);
+  for (; u < n_units; u += G) {
+    const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq;
     const int c0 = ct * COLS;
-    DcStage<T, ROWS, COLS, false> st;
-    P1Stage<T, ROWS + 2> sp;
-    dc2_load(st, dp2 + (int64_t)b * H2 * W2 * 32, code2 + (int64_t)b * H2 * W2 * 32, H2, W2, ROWS * rq, c0);
-    p1_band_load(sp, p1 + (int64_t)b * H1 * W1 * 16, H1, W1, ROWS * rq - 1, c0 - 1);
-    __syncthreads();   // previous unit's readers are done
     dc2_expand<T, ROWS, COLS, false, true>(st, ROWS * rq, c0, dc_s, bsum);
     p1_band_store(sp, p_s);
     __syncthreads();
+    issue(u + G < n_units ? u + G : u);    // next unit's loads fly under this unit's MFMAs (always issued: no branch)
     // wave wv contracts row wv of the unit (64 pixels = 2 bf16 k-steps / 16 fp32 k-steps)
     const int d = wv;
     if constexpr (sizeof(T) == 2) {
@@ -729,14 +908,19 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
           const bf16x4 hi = lds_tr16(&dc_s[(d * COLS + cb + 4 + q) * S32 + 16 * i + 4 * p]);
           a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         }
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        bf16x8 bb[2];
+        auto bfrag = [&](int tap) {
           const int kh = tap / 3, kw = tap % 3;
           const bf16x4 lo = lds_tr16(&p_s[((d + kh) * WP + cb + kw + q) * S16 + 4 * p]);
           const bf16x4 hi = lds_tr16(&p_s[((d + kh) * WP + cb + kw + 4 + q) * S16 + 4 * p]);
-          const bf16x8 bb = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        bb[0] = bfrag(0);
 #pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i][tap] = mfma16(a[i], bb, acc[i][tap]);
+        for (int tap = 0; tap < 9; ++tap) {      // the next tap's fragment is read before this tap's MFMAs issue
+          if (tap + 1 < 9) bb[(tap + 1) & 1] = bfrag(tap + 1);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[i][tap] = mfma16(a[i], bb[tap & 1], acc[i][tap]);
         }
       }
     } else {
@@ -755,6 +939,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
         }
       }
     }
+    __syncthreads();   // this unit's readers are done: the LDS images may be rebuilt
   }
   // ---- cross-wave reduction in fixed order (wave 0 stores, waves 1..3 add in turn: each element is touched by the
   //      same lane position in every wave) and slab write.  slab layout: [o 32][tap 9][ci 16] then 32 bias sums.
@@ -812,6 +997,9 @@ inline int conv2w_blocks(int n_units) { return n_units < 1024 ? n_units : 1024; 
 // on the first, un-captured launch only; the size per kernel instantiation never changes).
 inline int bd_tiles(int B, int H1, int W1) { return B * ((H1 + ROWS - 1) / ROWS) * ((W1 + BD_COLS - 1) / BD_COLS); }
 inline int bd_blocks(int n_tiles) { return n_tiles < 768 ? n_tiles : 768; }     // persistent: 3 workgroups per CU
+
+// the conv2 kernels address their tensors through 32-bit buffer offsets (see make_rsrc): largest tensor < 2 GiB
+inline bool fits_buffer_addressing(int B, int H1, int W1) { return (int64_t)B * H1 * W1 * 16 * 4 < (int64_t)1 << 31; }
 
 template <typename K>
 inline void allow_lds(K kernel, size_t bytes) {
@@ -886,20 +1074,22 @@ extern "C" int gdm_simnn_conv2_pack(const float* w, int dtype, void* pack, void*
 extern "C" int gdm_simnn_conv2_fwd(const void* p1, const void* pack, const float* bias, int B, int H1, int W1, void* p2,
                                    uint8_t* code2, int dtype, void* stream) {
   GDM_REQUIRE(p1 && pack && bias && p2 && code2, "gdm_simnn_conv2_fwd: null pointer");
-  GDM_REQUIRE(B > 0 && B <= 65535 && H1 >= 2 && W1 >= 2 && gdm_dtype_ok(dtype), "gdm_simnn_conv2_fwd: bad arguments");
+  GDM_REQUIRE(B > 0 && H1 >= 2 && W1 >= 2 && gdm_dtype_ok(dtype), "gdm_simnn_conv2_fwd: bad arguments");
+  GDM_REQUIRE(fits_buffer_addressing(B, H1, W1), "gdm_simnn_conv2_fwd: batch of %d %dx%d maps exceeds 2 GiB per tensor", B, H1, W1);
   const int H2 = H1 / 2, W2 = W1 / 2;
-  dim3 grid((2 * W2 + COLS - 1) / COLS, (2 * H2 + ROWS - 1) / ROWS, B);
-  GDM_REQUIRE(grid.y <= 65535, "gdm_simnn_conv2_fwd: H too large");
+  const int n_ctiles = (2 * W2 + COLS - 1) / COLS;
+  const int n_tiles = B * ((2 * H2 + ROWS - 1) / ROWS) * n_ctiles;
+  dim3 grid((unsigned)(n_tiles < 768 ? n_tiles : 768));        // persistent: 3 workgroups per CU
   hipStream_t s = (hipStream_t)stream;
   if (dtype == GDM_BF16) {
     const size_t sm = (size_t)(C2<__bf16>::IN_ELEMS + C2<__bf16>::WF_ELEMS) * 2;
     hipLaunchKernelGGL(conv2_fwd_kernel<__bf16>, grid, dim3(256), sm, s, (const __bf16*)p1, (const __bf16*)pack, bias,
-                       H1, W1, H2, W2, (__bf16*)p2, code2);
+                       H1, W1, H2, W2, n_ctiles, n_tiles, (__bf16*)p2, code2);
   } else {
     const size_t sm = (size_t)(C2<float>::IN_ELEMS + C2<float>::WF_ELEMS) * 4;
     allow_lds(conv2_fwd_kernel<float>, sm);
     hipLaunchKernelGGL(conv2_fwd_kernel<float>, grid, dim3(256), sm, s, (const float*)p1, (const float*)pack, bias, H1,
-                       W1, H2, W2, (float*)p2, code2);
+                       W1, H2, W2, n_ctiles, n_tiles, (float*)p2, code2);
   }
   GDM_LAUNCH_OK("gdm_simnn_conv2_fwd");
   return GDM_OK;
@@ -927,6 +1117,7 @@ extern "C" int gdm_simnn_conv2_bwd_data(const void* dp2, const uint8_t* code2, c
                                         void* dp1, int dtype, void* stream) {
   GDM_REQUIRE(dp2 && code2 && pack && dp1, "gdm_simnn_conv2_bwd_data: null pointer");
   GDM_REQUIRE(B > 0 && H1 >= 2 && W1 >= 2 && gdm_dtype_ok(dtype), "gdm_simnn_conv2_bwd_data: bad arguments");
+  GDM_REQUIRE(fits_buffer_addressing(B, H1, W1), "gdm_simnn_conv2_bwd_data: batch of %d %dx%d maps exceeds 2 GiB per tensor", B, H1, W1);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == GDM_BF16)
     return launch_bwd_data<__bf16, false>(dp2, code2, pack, B, H1, W1, dp1, nullptr, nullptr, nullptr, 0, 0, 0,
@@ -949,6 +1140,8 @@ extern "C" int gdm_simnn_conv2_bwd_fused(const void* dp2, const uint8_t* code2, 
               "gdm_simnn_conv2_bwd_fused: (H1,W1)=(%d,%d) does not belong to a %dx%d input", H1, W1, H, W);
   GDM_REQUIRE(bsplit >= 0 && bsplit <= B && (bsplit == B || x1 != nullptr),
               "gdm_simnn_conv2_bwd_fused: second input pointer missing");
+  GDM_REQUIRE(fits_buffer_addressing(B, H1, W1), "gdm_simnn_conv2_bwd_fused: batch of %d %dx%d maps exceeds 2 GiB per tensor",
+              B, H1, W1);
   if (!workspace || workspace_bytes < gdm_simnn_conv2_bwd_fused_workspace_bytes(B, H1, W1)) {
     gdm_set_error("gdm_simnn_conv2_bwd_fused: workspace too small");
     return GDM_EWORKSPACE;
@@ -991,6 +1184,7 @@ extern "C" int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2,
                                           void* stream) {
   GDM_REQUIRE(dp2 && code2 && p1 && dw && db, "gdm_simnn_conv2_bwd_weight: null pointer");
   GDM_REQUIRE(B > 0 && H1 >= 2 && W1 >= 2 && gdm_dtype_ok(dtype), "gdm_simnn_conv2_bwd_weight: bad arguments");
+  GDM_REQUIRE(fits_buffer_addressing(B, H1, W1), "gdm_simnn_conv2_bwd_weight: batch of %d %dx%d maps exceeds 2 GiB per tensor", B, H1, W1);
   if (!workspace || workspace_bytes < gdm_simnn_conv2_bwd_weight_workspace_bytes(B, H1, W1)) {
     gdm_set_error("gdm_simnn_conv2_bwd_weight: workspace too small");
     return GDM_EWORKSPACE;
@@ -1022,3 +1216,9 @@ extern "C" int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2,
   GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_weight");
   return GDM_OK;
 }
+
+#ifdef GDM_STAMPS
+extern "C" int gdm_debug_read_stamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(gdm_stamp_buf), sizeof(unsigned long long) * n);
+}
+#endif
