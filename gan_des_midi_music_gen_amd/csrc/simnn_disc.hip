@@ -406,6 +406,8 @@ __device__ __forceinline__ void dc2_load(DcStage<T, NR, NC, HALO>& st, rsrc_t dp
   }
 }
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
 template <typename T, int NR, int NC, bool HALO, bool WITH_BSUM>
 __device__ __forceinline__ void dc2_expand(const DcStage<T, NR, NC, HALO>& st, int r_first, int c_first,
                                            T* __restrict__ dc_s, float* bsum) {
@@ -419,30 +421,55 @@ __device__ __forceinline__ void dc2_expand(const DcStage<T, NR, NC, HALO>& st, i
     if (it >= S::NPR * S::NPC) continue;
     const int pr = pr_first + it / S::NPC, pc = pc_first + it % S::NPC;
     const uint64_t cd = st.cd[k];
-    float g[8];
     if constexpr (sizeof(T) == 2) {
-      const bf16x8 v = *(const bf16x8*)&st.g[k][0];
+      // Packed 16-bit arithmetic on (code, gradient) pairs, two channels per VGPR: the gradient words stay bf16 and
+      // the selection is an AND with a 0xffff/0 lane mask  ((code ^ pos) - 1) >> 15  -- 4 VALU per pair and position
+      // instead of a byte extract, a compare, a select and two conversions per channel and position.
+      const uint32_t clo = (uint32_t)cd, chi = (uint32_t)(cd >> 32);
+      uint32_t c16[4], gw[4];
+      c16[0] = __builtin_amdgcn_perm(0u, clo, 0x0c010c00u);     // {code0, code1} in the two 16-bit lanes
+      c16[1] = __builtin_amdgcn_perm(0u, clo, 0x0c030c02u);
+      c16[2] = __builtin_amdgcn_perm(0u, chi, 0x0c010c00u);
+      c16[3] = __builtin_amdgcn_perm(0u, chi, 0x0c030c02u);
+      const u32x4 gv = __builtin_bit_cast(u32x4, st.g[k][0]);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) g[e] = (float)v[e];
+      for (int w = 0; w < 4; ++w) gw[w] = gv[w];
+      if (WITH_BSUM) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const s16x2 lv = (__builtin_bit_cast(s16x2, c16[w]) - (s16x2){4, 4}) >> 15;     // code < 4: channel is live
+          const uint32_t g = gw[w] & __builtin_bit_cast(uint32_t, lv);
+          bsum[2 * w] += __builtin_bit_cast(float, g << 16);
+          bsum[2 * w + 1] += __builtin_bit_cast(float, g & 0xffff0000u);
+        }
+      }
+#pragma unroll
+      for (int pos = 0; pos < 4; ++pos) {
+        const int rl = 2 * pr + (pos >> 1) - r_first, cl = 2 * pc + (pos & 1) - c_first;
+        if (rl >= 0 && rl < NR && cl >= 0 && cl < NC) {
+          u32x4 v;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const s16x2 tq = __builtin_bit_cast(s16x2, c16[w] ^ (0x00010001u * (uint32_t)pos));
+            const s16x2 m = (tq - (s16x2){1, 1}) >> 15;
+            v[w] = gw[w] & __builtin_bit_cast(uint32_t, m);
+          }
+          *(u32x4*)(dc_s + (rl * NC + cl) * S32 + 8 * og) = v;
+        }
+      }
     } else {
+      float g[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { g[e] = st.g[k][0][e]; g[4 + e] = st.g[k][1][e]; }
-    }
-    if (WITH_BSUM) {
+      if (WITH_BSUM) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bsum[e] += (((cd >> (8 * e)) & 0xff) < 4) ? g[e] : 0.f;
-    }
+        for (int e = 0; e < 8; ++e) bsum[e] += (((cd >> (8 * e)) & 0xff) < 4) ? g[e] : 0.f;
+      }
 #pragma unroll
-    for (int pos = 0; pos < 4; ++pos) {
-      const int rl = 2 * pr + (pos >> 1) - r_first, cl = 2 * pc + (pos & 1) - c_first;
-      if (rl >= 0 && rl < NR && cl >= 0 && cl < NC) {
-        T* dst = dc_s + (rl * NC + cl) * S32 + 8 * og;
-        if constexpr (sizeof(T) == 2) {
-          bf16x8 v;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (__bf16)((int)((cd >> (8 * e)) & 0xff) == pos ? g[e] : 0.f);
-          *(bf16x8*)dst = v;
-        } else {
+      for (int pos = 0; pos < 4; ++pos) {
+        const int rl = 2 * pr + (pos >> 1) - r_first, cl = 2 * pc + (pos & 1) - c_first;
+        if (rl >= 0 && rl < NR && cl >= 0 && cl < NC) {
+          T* dst = dc_s + (rl * NC + cl) * S32 + 8 * og;
 #pragma unroll
           for (int e = 0; e < 8; ++e) dst[e] = (int)((cd >> (8 * e)) & 0xff) == pos ? g[e] : 0.f;
         }
@@ -620,85 +647,174 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
 
 // ---------------------------------------------------------------------------------- conv2 backward (data [+ conv1 dW])
 // dp1[ih][iw][ci] = sum_{ah,aw,o} dc2[ih-1+ah][iw-1+aw][o] * Wb[ci][(ah*3+aw)*32 + o]        (K = 288)
-// Tile = 4 rows x 64 columns per 256-thread workgroup, wave w owns row w (4 MFMA column tiles): half the LDS of the
-// 128-column tile, so four workgroups (16 waves) share a CU and hide each other's load/expand phases.
+// where dc2 is the sparse full-resolution gradient  dc2[r][c][o] = (code2[r/2][c/2][o] == 2(r&1)+(c&1)) ? dp2[..] : 0.
+//
+// A persistent 256-thread workgroup walks STRIPS (image b, 64-column tile ct) top to bottom in steps of 4 output
+// rows; wave w owns row w of the step (4 MFMA column tiles).  dc2 lives in an 8-row LDS ring: step rq needs conv rows
+// 4rq-1 .. 4rq+4 and only the two pooled rows 2rq+1, 2rq+2 (conv rows 4rq+2 .. 4rq+5) are new, so every dp2/code2
+// element of the strip is fetched and expanded once (a stand-alone 4-row tile with halo re-expands 2.1x as much).  A
+// strip starts with the pseudo step rq = -1 (pooled rows -1 [zeros] and 0, no output).  The pooled rows of the next
+// step are fetched into registers right after this step's expansion (software prefetch across steps and strips);
+// every staging access is a buffer load/store whose out-of-image lanes read zeros / are dropped, so the step body has
+// no branch around memory operations.  The bf16 ring keeps a pixel's four 16-byte channel groups XOR-swizzled by its
+// column ((col>>2)&3 ^ 3*group&3): the B-fragment ds_read_b128 of 16 neighbouring pixels is then bank-conflict-free.
+//
 // FUSE: instead of (or besides) writing dp1, route it through conv1's ReLU/pool code and contract it with the input
 // window held in LDS:  dW1[c][kh][kw] += live * dp1[c] * x[2ih+dy-1+kh][2iw+dx-1+kw],  db1[c] += live * dp1[c];
 // the workgroup's 80 partial sums go to one slab (summed in fixed order by slab_sum_kernel).
-constexpr int BD_COLS = 64, BD_WP = BD_COLS + 2, BD_XW = 2 * BD_COLS + 4;
-#ifndef GDM_BD_PREFETCH
-#define GDM_BD_PREFETCH 1
-#endif
-constexpr bool BD_PREFETCH = GDM_BD_PREFETCH;
+constexpr int BD_COLS = 64;
+constexpr int BD_RING = 8;                     // conv rows in the LDS ring
+constexpr int BD_WPX = BD_COLS + 4;            // stored columns: band column cl = -1 .. 66 lives at index cl + 1
+constexpr int BD_NPC = BD_COLS / 2 + 2;        // pooled columns touching the band (c0/2 - 1 .. c0/2 + 32)
+constexpr int BD_ITEMS = 2 * BD_NPC;           // pooled pixels expanded per step
+constexpr int BD_DCIT = (BD_ITEMS * 4 + 255) / 256;
+constexpr int BD_XW = 256;                     // x-window row stride in LDS (power of two: cheap gather offsets)
+constexpr int BD_XCOLS = 2 * BD_COLS + 8;      // x-window columns 2c0-4 .. 2c0+131 (16-byte aligned start)
 template <typename T> struct BD {
-  static constexpr int DC_ELEMS = (ROWS + 2) * BD_WP * C2<T>::S32;
+  static constexpr int DC_ELEMS = BD_RING * BD_WPX * C2<T>::S32;
   static constexpr size_t lds_bytes(bool fuse) {
     return (size_t)(DC_ELEMS + C2<T>::WB_ELEMS) * sizeof(T) + (fuse ? (size_t)(XROWS * BD_XW + 4 * 80) * 4 : 0);
   }
 };
 
-// Everything a workgroup has to fetch from HBM for one tile, held in registers between "issue" and "consume":
-// the loads of tile t+1 are issued right after tile t's LDS image is complete, so their latency is covered by tile
-// t's MFMA + epilogue work (software prefetch one tile ahead; the kernel is persistent over tiles).
-template <typename T, bool FUSE> struct BdTileRegs {
-  static constexpr int XIT = (XROWS * BD_XW + 255) / 256;
-  DcStage<T, ROWS + 2, BD_WP, true> dc;
-  float xv[FUSE ? XIT : 1];
+// Everything a workgroup fetches from HBM for one step, held in registers between "issue" and "consume".
+template <typename T, bool FUSE, bool XVEC> struct BdStepRegs {
+  static constexpr int XIT = FUSE ? (XVEC ? (XROWS * (BD_XCOLS / 4) + 255) / 256 : (XROWS * BD_XCOLS + 255) / 256) : 1;
+  f32x4 g[BD_DCIT][sizeof(T) == 2 ? 1 : 2];
+  uint64_t cd[BD_DCIT];
+  f32x4 xv4[XVEC ? XIT : 1];
+  float xv[XVEC ? 1 : XIT];
   uint64_t codes[FUSE ? 4 : 1];
 };
 
-template <bool FUSE> struct BdRsrc {
+struct BdRsrc {
   rsrc_t dp2, code2, dp1, code1;
 };
 
-template <typename T, bool FUSE>
-__device__ __forceinline__ void bd_issue(BdTileRegs<T, FUSE>& rg, int u, int n_ctiles, int nrq, const BdRsrc<FUSE>& rs,
+template <typename T, bool FUSE, bool XVEC>
+__device__ __forceinline__ void bd_issue(BdStepRegs<T, FUSE, XVEC>& rg, int b, int c0, int rq, const BdRsrc& rs,
                                          int H1, int W1, int H2, int W2, const float* __restrict__ x0,
                                          const float* __restrict__ x1, int bsplit, int H, int W) {
-  constexpr int XW = BD_XW;
   const int t = threadIdx.x, lr = t & 15, wv = t >> 6;
-  const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq, b = u / (n_ctiles * nrq);
-  const int c0 = ct * BD_COLS;
-  dc2_load(rg.dc, rs.dp2, rs.code2, (uint32_t)b * H2 * W2 * 32, H2, W2, ROWS * rq - 1, c0 - 1);
+  const uint32_t img = (uint32_t)b * H2 * W2 * 32;
+#pragma unroll
+  for (int k = 0; k < BD_DCIT; ++k) {
+    const int i = t + 256 * k, item = i >> 2, og = i & 3;
+    const int pr = 2 * rq + 1 + item / BD_NPC, pc = (c0 >> 1) - 1 + item % BD_NPC;
+    const bool ok = item < BD_ITEMS && pr >= 0 && pr < H2 && pc >= 0 && pc < W2;
+    const uint32_t gi = img + (uint32_t)(pr * W2 + pc) * 32 + 8 * og;
+    rg.cd[k] = buf_load8(rs.code2, ok ? gi : BUF_OOB);
+    rg.g[k][0] = buf_load16(rs.dp2, ok ? gi * (uint32_t)sizeof(T) : BUF_OOB);
+    if constexpr (sizeof(T) == 4) rg.g[k][1] = buf_load16(rs.dp2, ok ? gi * 4u + 16u : BUF_OOB);
+  }
   if constexpr (FUSE) {
-    // the input image of sample b lives in one of two tensors (real | generated): one descriptor per tile
+    // the input image of sample b lives in one of two tensors (real | generated): one descriptor per step
     const float* xb = (b < bsplit) ? x0 + (int64_t)b * H * W : x1 + (int64_t)(b - bsplit) * H * W;
     const rsrc_t xr_ = make_rsrc(xb, (uint32_t)H * W * 4);
+    const int xr0 = 2 * ROWS * rq - 1, xc0 = 2 * c0 - 4;
+    if constexpr (XVEC) {
 #pragma unroll
-    for (int k = 0; k < BdTileRegs<T, FUSE>::XIT; ++k) {
-      const int i = t + 256 * k;
-      const int bc = i % XW, br = i / XW;
-      const int xr = 2 * ROWS * rq - 1 + br, xc = 2 * c0 - 1 + bc;
-      const bool ok = i < XROWS * XW && xr >= 0 && xr < H && xc >= 0 && xc < W;
-      rg.xv[k] = buf_load4(xr_, ok ? (uint32_t)(xr * W + xc) * 4u : BUF_OOB);
+      for (int k = 0; k < BdStepRegs<T, FUSE, XVEC>::XIT; ++k) {
+        const int i = t + 256 * k;
+        const int vc = i % (BD_XCOLS / 4), br = i / (BD_XCOLS / 4);
+        const int xr = xr0 + br, xc = xc0 + 4 * vc;            // W % 4 == 0: a vector is inside or outside as a whole
+        const bool ok = br < XROWS && xr >= 0 && xr < H && xc >= 0 && xc < W;
+        rg.xv4[k] = buf_load16(xr_, ok ? (uint32_t)(xr * W + xc) * 4u : BUF_OOB);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < BdStepRegs<T, FUSE, XVEC>::XIT; ++k) {
+        const int i = t + 256 * k;
+        const int bc = i % BD_XCOLS, br = i / BD_XCOLS;
+        const int xr = xr0 + br, xc = xc0 + bc;
+        const bool ok = br < XROWS && xr >= 0 && xr < H && xc >= 0 && xc < W;
+        rg.xv[k] = buf_load4(xr_, ok ? (uint32_t)(xr * W + xc) * 4u : BUF_OOB);
+      }
     }
     const int ih = ROWS * rq + wv;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int iw = c0 + 16 * j + lr;
-      rg.codes[j] = buf_load8(rs.code1, (ih < H1 && iw < W1) ? (uint32_t)((b * H1 + ih) * W1 + iw) * 8u : BUF_OOB);
+      rg.codes[j] =
+          buf_load8(rs.code1, (ih >= 0 && ih < H1 && iw < W1) ? (uint32_t)((b * H1 + ih) * W1 + iw) * 8u : BUF_OOB);
     }
   }
 }
 
-template <typename T, bool FUSE>
+// Registers of step rq -> ring rows 4rq+2 .. 4rq+5.  Lane = (pooled pixel, 8-channel group): up to four 16-byte records.
+template <typename T, bool FUSE, bool XVEC>
+__device__ __forceinline__ void bd_expand(const BdStepRegs<T, FUSE, XVEC>& rg, int rq, T* __restrict__ dc_s) {
+  constexpr int S32 = C2<T>::S32;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < BD_DCIT; ++k) {
+    const int i = t + 256 * k, item = i >> 2, og = i & 3;
+    if (item >= BD_ITEMS) continue;
+    const int prow = item / BD_NPC, pcol = item % BD_NPC;
+    const int slot = (ROWS * rq + 2 + 2 * prow) & (BD_RING - 1);       // even: slot + 1 never wraps
+    const uint64_t cd = rg.cd[k];
+    if constexpr (sizeof(T) == 2) {
+      // Packed 16-bit arithmetic on (code, gradient) pairs, two channels per VGPR: the gradient words stay bf16 and
+      // the selection is an AND with the 0xffff/0 lane mask  ((code ^ pos) - 1) >> 15.
+      const uint32_t clo = (uint32_t)cd, chi = (uint32_t)(cd >> 32);
+      uint32_t c16[4], gw[4];
+      c16[0] = __builtin_amdgcn_perm(0u, clo, 0x0c010c00u);     // {code0, code1} in the two 16-bit lanes
+      c16[1] = __builtin_amdgcn_perm(0u, clo, 0x0c030c02u);
+      c16[2] = __builtin_amdgcn_perm(0u, chi, 0x0c010c00u);
+      c16[3] = __builtin_amdgcn_perm(0u, chi, 0x0c030c02u);
+      const u32x4 gv = __builtin_bit_cast(u32x4, rg.g[k][0]);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) gw[w] = gv[w];
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int sc = 2 * pcol + dx;                                         // stored column
+        const int piece = ((sc >> 2) & 3) ^ ((3 * og) & 3);                   // swizzled 16-byte slot of the record
+        T* dst = dc_s + (slot * BD_WPX + sc) * S32 + 8 * piece;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const uint32_t pos = 2 * dy + dx;
+          u32x4 v;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const s16x2 tq = __builtin_bit_cast(s16x2, c16[w] ^ (0x00010001u * pos));
+            const s16x2 m = (tq - (s16x2){1, 1}) >> 15;
+            v[w] = gw[w] & __builtin_bit_cast(uint32_t, m);
+          }
+          *(u32x4*)(dst + dy * BD_WPX * S32) = v;
+        }
+      }
+    } else {
+      float g[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { g[e] = rg.g[k][0][e]; g[4 + e] = rg.g[k][1][e]; }
+#pragma unroll
+      for (int pos = 0; pos < 4; ++pos) {
+        T* dst = dc_s + ((slot + (pos >> 1)) * BD_WPX + 2 * pcol + (pos & 1)) * S32 + 8 * og;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[e] = (int)((cd >> (8 * e)) & 0xff) == pos ? g[e] : 0.f;
+      }
+    }
+  }
+}
+
+template <typename T, bool FUSE, bool XVEC>
 __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict__ dp2,
-                                                                const uint8_t* __restrict__ code2,
-                                                                const T* __restrict__ wb, int H1, int W1, int H2,
-                                                                int W2, int n_ctiles, int n_tiles,
-                                                                T* __restrict__ dp1,
-                                                                const uint64_t* __restrict__ code1,
-                                                                const float* __restrict__ x0,
-                                                                const float* __restrict__ x1, int bsplit, int H, int W,
-                                                                float* __restrict__ slabs) {
-  constexpr int S32 = C2<T>::S32, KP = C2<T>::KPB, WP = BD_WP, XW = BD_XW;
+                                                             const uint8_t* __restrict__ code2,
+                                                             const T* __restrict__ wb, int B, int H1, int W1, int H2,
+                                                             int W2, int n_ctiles, int nseg, int seg_len,
+                                                             int n_strips, T* __restrict__ dp1,
+                                                             const uint64_t* __restrict__ code1,
+                                                             const float* __restrict__ x0,
+                                                             const float* __restrict__ x1, int bsplit, int H, int W,
+                                                             float* __restrict__ slabs) {
+  constexpr int S32 = C2<T>::S32, KP = C2<T>::KPB, XW = BD_XW;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   T* dc_s = (T*)dyn_smem;
   T* w_s = dc_s + BD<T>::DC_ELEMS;
   float* x_s = (float*)(w_s + C2<T>::WB_ELEMS);          // FUSE only: [XROWS][XW]
   float* red = x_s + XROWS * XW;                          // FUSE only: [4][80]
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
-  const int nrq = (H1 + ROWS - 1) / ROWS;
+  const int nrq = (H1 + ROWS - 1) / ROWS, G = gridDim.x;
 
   float a1[4][4], bs[4];
 #pragma unroll
@@ -707,32 +823,48 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
 #pragma unroll
     for (int q = 0; q < 4; ++q) a1[r][q] = 0.f;
   }
-
-  const int B = n_tiles / (n_ctiles * nrq), G = gridDim.x;
-  BdRsrc<FUSE> rs;
+  STAMP_DECL;
+  BdRsrc rs;
   rs.dp2 = make_rsrc(dp2, (uint32_t)B * H2 * W2 * 32 * sizeof(T));
   rs.code2 = make_rsrc(code2, (uint32_t)B * H2 * W2 * 32);
   rs.dp1 = make_rsrc(dp1, dp1 ? (uint32_t)B * H1 * W1 * 16 * sizeof(T) : 0u);
   rs.code1 = make_rsrc(code1, FUSE ? (uint32_t)B * H1 * W1 * 8 : 0u);
-  STAMP_DECL;
   copy_to_lds(w_s, wb, C2<T>::WB_ELEMS);
-  BdTileRegs<T, FUSE> rg;
-  int u = blockIdx.x;                                       // host guarantees gridDim.x <= n_tiles
-  if (BD_PREFETCH) bd_issue<T, FUSE>(rg, u, n_ctiles, nrq, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
+
+  // work item s = (image b, row segment seg, column tile ct); a segment is seg_len steps and starts with a pseudo step
+  auto place = [&](int s_, int& b_, int& c0_, int& rq_first, int& rq_end) {
+    const int ct = s_ % n_ctiles, sg = (s_ / n_ctiles) % nseg;
+    b_ = s_ / (n_ctiles * nseg);
+    c0_ = ct * BD_COLS;
+    rq_first = sg * seg_len;
+    rq_end = min(rq_first + seg_len, nrq);
+  };
+  BdStepRegs<T, FUSE, XVEC> rg;
+  int s = blockIdx.x, b, c0, rq_first, rq_end;              // host guarantees gridDim.x <= n_strips
+  place(s, b, c0, rq_first, rq_end);
+  int rq = rq_first - 1;
+  bd_issue<T, FUSE, XVEC>(rg, b, c0, rq, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
   STAMP(6);
-  for (; u < n_tiles; u += G) {
-    if (!BD_PREFETCH) bd_issue<T, FUSE>(rg, u, n_ctiles, nrq, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
-    const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq, b = u / (n_ctiles * nrq);
-    const int c0 = ct * BD_COLS;
+  while (s < n_strips) {
     const int ih = ROWS * rq + wv;                          // this wave's output row
-    // ---- consume the prefetched registers into the LDS images of this tile
-    dc2_expand<T, ROWS + 2, WP, true, false>(rg.dc, ROWS * rq - 1, c0 - 1, dc_s, nullptr);
+    // ---- consume the prefetched registers into the LDS images of this step
+    bd_expand<T, FUSE, XVEC>(rg, rq, dc_s);
     uint64_t codes[FUSE ? 4 : 1];
     if constexpr (FUSE) {
+      if constexpr (XVEC) {
 #pragma unroll
-      for (int k = 0; k < BdTileRegs<T, FUSE>::XIT; ++k) {
-        const int i = t + 256 * k;
-        if (i < XROWS * XW) x_s[i] = rg.xv[k];
+        for (int k = 0; k < BdStepRegs<T, FUSE, XVEC>::XIT; ++k) {
+          const int i = t + 256 * k;
+          const int vc = i % (BD_XCOLS / 4), br = i / (BD_XCOLS / 4);
+          if (br < XROWS) *(f32x4*)&x_s[br * XW + 4 * vc] = rg.xv4[k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < BdStepRegs<T, FUSE, XVEC>::XIT; ++k) {
+          const int i = t + 256 * k;
+          const int bc = i % BD_XCOLS, br = i / BD_XCOLS;
+          if (br < XROWS) x_s[br * XW + bc] = rg.xv[k];
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) codes[j] = rg.codes[j];
@@ -740,86 +872,111 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
     STAMP(7);
     __syncthreads();
     STAMP(0);
-    // next tile's loads fly during the work below; issued on EVERY iteration (the last one re-reads its own, cache-hot
-    // tile) so that the loop has no branch around memory operations
-    if (BD_PREFETCH)
-      bd_issue<T, FUSE>(rg, u + G < n_tiles ? u + G : u, n_ctiles, nrq, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
+    // the next step's loads fly during the work below; issued on EVERY step (the very last one re-reads its own,
+    // cache-hot rows), so the step body has no branch around memory operations
+    int sn = s, bn = b, c0n = c0, rqn = rq + 1, rq_first_n = rq_first, rq_end_n = rq_end;
+    if (rqn == rq_end) {
+      sn = s + G;
+      if (sn < n_strips) {
+        place(sn, bn, c0n, rq_first_n, rq_end_n);
+        rqn = rq_first_n - 1;
+      } else {
+        rqn = rq;                                           // nothing left: re-read the current rows
+      }
+    }
+    bd_issue<T, FUSE, XVEC>(rg, bn, c0n, rqn, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
     STAMP(1);
 
-    f32x4 acc[4];
+    if (rq >= rq_first) {
+      f32x4 acc[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (sizeof(T) == 2) {
-      // one (flipped) tap = 32 channels per k-step; the fragments of k-step ks+1 are read before the MFMAs of ks issue
-      bf16x8 a[2], bb[2][4];
-      auto frags = [&](int ks, bf16x8& aa, bf16x8 (&bx)[4]) {
-        const int ah = ks / 3, aw = ks % 3;
-        aa = *(const bf16x8*)&w_s[lr * KP + 32 * ks + 8 * lg];
+      for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (sizeof(T) == 2) {
+        // one (flipped) tap = 32 channels per k-step; the fragments of k-step ks+1 are read before the MFMAs of ks issue
+        int cb[3], ro[3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bx[j] = *(const bf16x8*)&dc_s[((wv + ah) * WP + 16 * j + lr + aw) * S32 + 8 * lg];
-      };
-      frags(0, a[0], bb[0]);
+        for (int aw = 0; aw < 3; ++aw) {
+          const int sc = lr + aw + 1;                            // + 16 j: leaves (sc >> 2) & 3 unchanged
+          cb[aw] = sc * S32 + 8 * (((sc >> 2) & 3) ^ ((3 * lg) & 3));
+        }
 #pragma unroll
-      for (int ks = 0; ks < 9; ++ks) {
-        if (ks + 1 < 9) frags(ks + 1, a[(ks + 1) & 1], bb[(ks + 1) & 1]);
+        for (int ah = 0; ah < 3; ++ah) ro[ah] = ((ih - 1 + ah) & (BD_RING - 1)) * BD_WPX * S32;
+        bf16x8 a[2], bb[2][4];
+        auto frags = [&](int ks, bf16x8& aa, bf16x8 (&bx)[4]) {
+          const int ah = ks / 3, aw = ks % 3;
+          aa = *(const bf16x8*)&w_s[lr * KP + 32 * ks + 8 * lg];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = mfma16(a[ks & 1], bb[ks & 1][j], acc[j]);
-      }
-    } else {
+          for (int j = 0; j < 4; ++j) bx[j] = *(const bf16x8*)&dc_s[ro[ah] + cb[aw] + 16 * j * S32];
+        };
+        frags(0, a[0], bb[0]);
+#pragma unroll
+        for (int ks = 0; ks < 9; ++ks) {
+          if (ks + 1 < 9) frags(ks + 1, a[(ks + 1) & 1], bb[(ks + 1) & 1]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = mfma16(a[ks & 1], bb[ks & 1][j], acc[j]);
+        }
+      } else {
 #pragma unroll 2
-      for (int ks = 0; ks < 72; ++ks) {
-        const int tap = ks >> 3, o = 4 * (ks & 7) + lg;
-        const int ah = tap / 3, aw = tap % 3;
-        const float a = w_s[lr * KP + 4 * ks + lg];
+        for (int ks = 0; ks < 72; ++ks) {
+          const int tap = ks >> 3, o = 4 * (ks & 7) + lg;
+          const int ah = tap / 3, aw = tap % 3;
+          const float a = w_s[lr * KP + 4 * ks + lg];
+          const int rbase = ((ih - 1 + ah) & (BD_RING - 1)) * BD_WPX;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float bb = dc_s[(rbase + 16 * j + lr + aw + 1) * S32 + o];
+            acc[j] = mfma16(a, bb, acc[j]);
+          }
+        }
+      }
+      STAMP(2);
+      // C layout: col (lr) = pixel, row (4*lg + r) = input channel ci
+      if (dp1 != nullptr) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float bb = dc_s[((wv + ah) * WP + 16 * j + lr + aw) * S32 + o];
-          acc[j] = mfma16(a, bb, acc[j]);
+          const int iw = c0 + 16 * j + lr;
+          const bool ok = ih < H1 && iw < W1;
+          const uint32_t di = (uint32_t)((b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
+          if constexpr (sizeof(T) == 2) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[j][r];
+            buf_store8(rs.dp1, ok ? di * 2u : BUF_OOB, __builtin_bit_cast(uint64_t, v));
+          } else {
+            buf_store16(rs.dp1, ok ? di * 4u : BUF_OOB, acc[j]);
+          }
         }
       }
-    }
-    STAMP(2);
-    // C layout: col (lr) = pixel, row (4*lg + r) = input channel ci
-    if (dp1 != nullptr) {
+      STAMP(3);
+      if constexpr (FUSE) {
+        // x window of pixel (row wv, column cl) starts at x_s[2 wv][2 cl + 3]; position (dy, dx) moves it by dy rows and
+        // dx columns: offset = dx + 256 dy = (pos * 129) & 0x101
+        const float* xrow = x_s + 2 * wv * XW + 2 * lr + 3;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int iw = c0 + 16 * j + lr;
-        const bool ok = ih < H1 && iw < W1;
-        const uint32_t di = (uint32_t)((b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
-        if constexpr (sizeof(T) == 2) {
-          bf16x4 v;
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t pf = (uint32_t)codes[j] >> (8 * lg);                 // 2-bit positions of channels 4lg..4lg+3
+          const uint32_t lv = (uint32_t)(codes[j] >> 32) >> (4 * lg);         // their live bits
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[j][r];
-          buf_store8(rs.dp1, ok ? di * 2u : BUF_OOB, __builtin_bit_cast(uint64_t, v));
-        } else {
-          buf_store16(rs.dp1, ok ? di * 4u : BUF_OOB, acc[j]);
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t pos = (pf >> (2 * r)) & 3u;
+            const uint32_t live = (uint32_t)((int32_t)(lv << (31 - r)) >> 31);            // 0 or ~0
+            const float av = acc[j][r];      // (bit_cast straight from a vector element reads element 0)
+            const float g = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, av) & live);
+            const float* xp = xrow + 32 * j + ((pos * 129u) & 0x101u);
+            a1[r][0] = fmaf(g, xp[0], a1[r][0]);
+            a1[r][1] = fmaf(g, xp[1], a1[r][1]);
+            a1[r][2] = fmaf(g, xp[XW], a1[r][2]);
+            a1[r][3] = fmaf(g, xp[XW + 1], a1[r][3]);
+            bs[r] += g;
+          }
+          __builtin_amdgcn_sched_barrier(0);   // keep the LDS gathers of one column tile from piling up across tiles
         }
       }
+      STAMP(4);
     }
-    STAMP(3);
-    if constexpr (FUSE) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int cl = 16 * j + lr;
-        const uint64_t code = codes[j];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = 4 * lg + r;
-          const float g = ((code >> (32 + c)) & 1) ? acc[j][r] : 0.f;
-          const int pos = (int)((code >> (2 * c)) & 3);
-          const float* xp = x_s + (2 * wv + (pos >> 1)) * XW + 2 * cl + (pos & 1);
-          a1[r][0] = fmaf(g, xp[0], a1[r][0]);
-          a1[r][1] = fmaf(g, xp[1], a1[r][1]);
-          a1[r][2] = fmaf(g, xp[XW], a1[r][2]);
-          a1[r][3] = fmaf(g, xp[XW + 1], a1[r][3]);
-          bs[r] += g;
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the 16 LDS gathers of one column tile from piling up across tiles
-      }
-    }
-    STAMP(4);
-    __syncthreads();     // every wave is done with this tile's LDS images
+    __syncthreads();     // every wave is done with this step's LDS images
     STAMP(5);
+    s = sn; b = bn; c0 = c0n; rq = rqn; rq_first = rq_first_n; rq_end = rq_end_n;
   }
   STAMP_FLUSH;
   if constexpr (FUSE) {
@@ -993,21 +1150,40 @@ inline int conv1_slabs(int64_t total) {
 }
 inline int conv2w_blocks(int n_units) { return n_units < 1024 ? n_units : 1024; }
 
-// Raise a kernel's dynamic-LDS limit once per process (not a stream operation: kept out of graph capture by doing it
-// on the first, un-captured launch only; the size per kernel instantiation never changes).
-inline int bd_tiles(int B, int H1, int W1) { return B * ((H1 + ROWS - 1) / ROWS) * ((W1 + BD_COLS - 1) / BD_COLS); }
-inline int bd_blocks(int n_tiles) { return n_tiles < 768 ? n_tiles : 768; }     // persistent: 3 workgroups per CU
+// conv2 backward-data work decomposition: items = (image, row segment, 64-column tile).  Whole-height strips when
+// they fill the chip (2 resident workgroups per CU x 256 CUs); small batches are cut into row segments (each pays one
+// pseudo step).  A pure function of the shapes: the slab count of the fused variant must be reproducible by _finish.
+struct BdPlan { int n_ctiles, nseg, seg_len, n_items, blocks; };
+inline BdPlan bd_plan(int B, int H1, int W1, bool fuse) {
+  BdPlan p;
+  const int nrq = (H1 + ROWS - 1) / ROWS;
+  p.n_ctiles = (W1 + BD_COLS - 1) / BD_COLS;
+  const int64_t strips = (int64_t)B * p.n_ctiles;
+  int nseg = (int)((512 + strips - 1) / strips);
+  const int max_seg = nrq / 2 > 1 ? nrq / 2 : 1;            // at least two steps per segment
+  nseg = nseg < 1 ? 1 : (nseg > max_seg ? max_seg : nseg);
+  p.seg_len = (nrq + nseg - 1) / nseg;
+  p.nseg = (nrq + p.seg_len - 1) / p.seg_len;
+  p.n_items = (int)(strips * p.nseg);
+  const int cap = fuse ? 512 : 768;
+  p.blocks = p.n_items < cap ? p.n_items : cap;
+  return p;
+}
 
 // the conv2 kernels address their tensors through 32-bit buffer offsets (see make_rsrc): largest tensor < 2 GiB
 inline bool fits_buffer_addressing(int B, int H1, int W1) { return (int64_t)B * H1 * W1 * 16 * 4 < (int64_t)1 << 31; }
 
+// Raise a kernel's dynamic-LDS limit once per kernel and process (not a stream operation: kept out of graph capture
+// by doing it on the first, un-captured launch only; the size per kernel never changes).  Keyed by the kernel's
+// address: template instantiations that share a signature share K.
 template <typename K>
 inline void allow_lds(K kernel, size_t bytes) {
-  static bool done = false;    // one static per template instantiation = per kernel
-  if (!done) {
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    done = true;
-  }
+  static const void* done[16];
+  static int n_done = 0;
+  for (int i = 0; i < n_done; ++i)
+    if (done[i] == (const void*)kernel) return;
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (n_done < 16) done[n_done++] = (const void*)kernel;
 }
 
 }  // namespace
@@ -1101,13 +1277,21 @@ int launch_bwd_data(const void* dp2, const uint8_t* code2, const void* pack, int
                     const uint64_t* code1, const float* x0, const float* x1, int bsplit, int H, int W, float* slabs,
                     hipStream_t s) {
   const int H2 = H1 / 2, W2 = W1 / 2;
-  const int n_ctiles = (W1 + BD_COLS - 1) / BD_COLS;
-  const int n_tiles = bd_tiles(B, H1, W1);
+  const BdPlan pl = bd_plan(B, H1, W1, FUSE);
   const size_t sm = BD<T>::lds_bytes(FUSE);
-  allow_lds(conv2_bwd_data_kernel<T, FUSE>, sm);
-  hipLaunchKernelGGL((conv2_bwd_data_kernel<T, FUSE>), dim3(bd_blocks(n_tiles)), dim3(256), sm, s, (const T*)dp2,
-                     code2, (const T*)pack + C2<T>::WF_ELEMS, H1, W1, H2, W2, n_ctiles, n_tiles, (T*)dp1, code1, x0,
-                     x1, bsplit, H, W, slabs);
+  // 16-byte x-window loads need rows that start on 16-byte boundaries
+  const bool xvec = FUSE && W % 4 == 0 && (((uintptr_t)x0 | (uintptr_t)x1) & 15) == 0;
+#define GDM_BD_LAUNCH(XV)                                                                                              \
+  allow_lds(conv2_bwd_data_kernel<T, FUSE, XV>, sm);                                                                   \
+  hipLaunchKernelGGL((conv2_bwd_data_kernel<T, FUSE, XV>), dim3(pl.blocks), dim3(256), sm, s, (const T*)dp2, code2,    \
+                     (const T*)pack + C2<T>::WF_ELEMS, B, H1, W1, H2, W2, pl.n_ctiles, pl.nseg, pl.seg_len, pl.n_items, \
+                     (T*)dp1, code1, x0, x1, bsplit, H, W, slabs)
+  if constexpr (FUSE) {
+    if (xvec) { GDM_BD_LAUNCH(true); } else { GDM_BD_LAUNCH(false); }
+  } else {
+    GDM_BD_LAUNCH(false);
+  }
+#undef GDM_BD_LAUNCH
   GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_data");
   return GDM_OK;
 }
@@ -1127,7 +1311,7 @@ extern "C" int gdm_simnn_conv2_bwd_data(const void* dp2, const uint8_t* code2, c
 }
 
 extern "C" size_t gdm_simnn_conv2_bwd_fused_workspace_bytes(int B, int H1, int W1) {
-  return (size_t)(bd_blocks(bd_tiles(B, H1, W1)) + 65) * 80 * sizeof(float);
+  return (size_t)(bd_plan(B, H1, W1, true).blocks + 65) * 80 * sizeof(float);
 }
 
 extern "C" int gdm_simnn_conv2_bwd_fused(const void* dp2, const uint8_t* code2, const void* pack, int B, int H1, int W1,
@@ -1164,7 +1348,7 @@ extern "C" int gdm_simnn_conv2_bwd_fused_finish(int B, int H1, int W1, float* dw
     return GDM_EWORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int nblocks = bd_blocks(bd_tiles(B, H1, W1));
+  const int nblocks = bd_plan(B, H1, W1, true).blocks;
   float* slabs = (float*)workspace;
   float* scratch = slabs + (size_t)nblocks * 80;
   float* sums = scratch + 64 * 80;
