@@ -650,14 +650,15 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
 // where dc2 is the sparse full-resolution gradient  dc2[r][c][o] = (code2[r/2][c/2][o] == 2(r&1)+(c&1)) ? dp2[..] : 0.
 //
 // A persistent 256-thread workgroup walks STRIPS (image b, 64-column tile ct) top to bottom in steps of 4 output
-// rows; wave w owns row w of the step (4 MFMA column tiles).  dc2 lives in an 8-row LDS ring: step rq needs conv rows
+// rows; wave w owns the 16 columns of column tile w (4 rows = 4 accumulators).  dc2 lives in an 8-row LDS ring: step rq needs conv rows
 // 4rq-1 .. 4rq+4 and only the two pooled rows 2rq+1, 2rq+2 (conv rows 4rq+2 .. 4rq+5) are new, so every dp2/code2
 // element of the strip is fetched and expanded once (a stand-alone 4-row tile with halo re-expands 2.1x as much).  A
 // strip starts with the pseudo step rq = -1 (pooled rows -1 [zeros] and 0, no output).  The pooled rows of the next
 // step are fetched into registers right after this step's expansion (software prefetch across steps and strips);
 // every staging access is a buffer load/store whose out-of-image lanes read zeros / are dropped, so the step body has
 // no branch around memory operations.  The bf16 ring keeps a pixel's four 16-byte channel groups XOR-swizzled by its
-// column ((col>>2)&3 ^ 3*group&3): the B-fragment ds_read_b128 of 16 neighbouring pixels is then bank-conflict-free.
+// column (group ^ ((col >> 1) & 2)): the B-fragment ds_read_b128 of 16 neighbouring pixels (64-byte records, lane
+// groups {0-3,12-15,20-27}, ...) is then bank-conflict-free for every column offset (searched exhaustively).
 //
 // FUSE: instead of (or besides) writing dp1, route it through conv1's ReLU/pool code and contract it with the input
 // window held in LDS:  dW1[c][kh][kw] += live * dp1[c] * x[2ih+dy-1+kh][2iw+dx-1+kw],  db1[c] += live * dp1[c];
@@ -691,18 +692,28 @@ struct BdRsrc {
   rsrc_t dp2, code2, dp1, code1;
 };
 
+// Per-thread constants of the staging pattern (they depend on the lane only, never on the step): computed once so
+// that issuing a step's loads costs a handful of VALU per load.
+template <bool FUSE, bool XVEC> struct BdLane {
+  static constexpr int XIT = FUSE ? (XVEC ? (XROWS * (BD_XCOLS / 4) + 255) / 256 : (XROWS * BD_XCOLS + 255) / 256) : 1;
+  uint32_t dc_off[BD_DCIT];      // (prow * W2 + pcol) * 32 + 8 og
+  int dc_prow[BD_DCIT], dc_pcol[BD_DCIT];   // prow = 99 marks a lane without an item
+  uint32_t x_off[XIT];           // (br * W + bc) * 4
+  int x_br[XIT], x_bc[XIT];      // br = 99 marks a lane without an element
+};
+
 template <typename T, bool FUSE, bool XVEC>
-__device__ __forceinline__ void bd_issue(BdStepRegs<T, FUSE, XVEC>& rg, int b, int c0, int rq, const BdRsrc& rs,
-                                         int H1, int W1, int H2, int W2, const float* __restrict__ x0,
-                                         const float* __restrict__ x1, int bsplit, int H, int W) {
+__device__ __forceinline__ void bd_issue(BdStepRegs<T, FUSE, XVEC>& rg, const BdLane<FUSE, XVEC>& ln, int b, int c0,
+                                         int rq, const BdRsrc& rs, int H1, int W1, int H2, int W2,
+                                         const float* __restrict__ x0, const float* __restrict__ x1, int bsplit, int H,
+                                         int W) {
   const int t = threadIdx.x, lr = t & 15, wv = t >> 6;
-  const uint32_t img = (uint32_t)b * H2 * W2 * 32;
+  const int pr0 = 2 * rq + 1, pc0 = (c0 >> 1) - 1;
+  const uint32_t base = (uint32_t)b * H2 * W2 * 32 + (uint32_t)(pr0 * W2 + pc0) * 32;   // may wrap: only used when valid
 #pragma unroll
   for (int k = 0; k < BD_DCIT; ++k) {
-    const int i = t + 256 * k, item = i >> 2, og = i & 3;
-    const int pr = 2 * rq + 1 + item / BD_NPC, pc = (c0 >> 1) - 1 + item % BD_NPC;
-    const bool ok = item < BD_ITEMS && pr >= 0 && pr < H2 && pc >= 0 && pc < W2;
-    const uint32_t gi = img + (uint32_t)(pr * W2 + pc) * 32 + 8 * og;
+    const bool ok = (unsigned)(pr0 + ln.dc_prow[k]) < (unsigned)H2 && (unsigned)(pc0 + ln.dc_pcol[k]) < (unsigned)W2;
+    const uint32_t gi = base + ln.dc_off[k];
     rg.cd[k] = buf_load8(rs.code2, ok ? gi : BUF_OOB);
     rg.g[k][0] = buf_load16(rs.dp2, ok ? gi * (uint32_t)sizeof(T) : BUF_OOB);
     if constexpr (sizeof(T) == 4) rg.g[k][1] = buf_load16(rs.dp2, ok ? gi * 4u + 16u : BUF_OOB);
@@ -712,45 +723,36 @@ __device__ __forceinline__ void bd_issue(BdStepRegs<T, FUSE, XVEC>& rg, int b, i
     const float* xb = (b < bsplit) ? x0 + (int64_t)b * H * W : x1 + (int64_t)(b - bsplit) * H * W;
     const rsrc_t xr_ = make_rsrc(xb, (uint32_t)H * W * 4);
     const int xr0 = 2 * ROWS * rq - 1, xc0 = 2 * c0 - 4;
-    if constexpr (XVEC) {
+    const uint32_t xbase = (uint32_t)(xr0 * W + xc0) * 4u;
 #pragma unroll
-      for (int k = 0; k < BdStepRegs<T, FUSE, XVEC>::XIT; ++k) {
-        const int i = t + 256 * k;
-        const int vc = i % (BD_XCOLS / 4), br = i / (BD_XCOLS / 4);
-        const int xr = xr0 + br, xc = xc0 + 4 * vc;            // W % 4 == 0: a vector is inside or outside as a whole
-        const bool ok = br < XROWS && xr >= 0 && xr < H && xc >= 0 && xc < W;
-        rg.xv4[k] = buf_load16(xr_, ok ? (uint32_t)(xr * W + xc) * 4u : BUF_OOB);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < BdStepRegs<T, FUSE, XVEC>::XIT; ++k) {
-        const int i = t + 256 * k;
-        const int bc = i % BD_XCOLS, br = i / BD_XCOLS;
-        const int xr = xr0 + br, xc = xc0 + bc;
-        const bool ok = br < XROWS && xr >= 0 && xr < H && xc >= 0 && xc < W;
-        rg.xv[k] = buf_load4(xr_, ok ? (uint32_t)(xr * W + xc) * 4u : BUF_OOB);
-      }
+    for (int k = 0; k < BdLane<FUSE, XVEC>::XIT; ++k) {
+      // XVEC: W % 4 == 0, a 4-column vector is inside or outside the image as a whole
+      const bool ok = (unsigned)(xr0 + ln.x_br[k]) < (unsigned)H && (unsigned)(xc0 + ln.x_bc[k]) < (unsigned)W;
+      const uint32_t off = ok ? xbase + ln.x_off[k] : BUF_OOB;
+      if constexpr (XVEC) rg.xv4[k] = buf_load16(xr_, off);
+      else rg.xv[k] = buf_load4(xr_, off);
     }
-    const int ih = ROWS * rq + wv;
+    // conv1 codes of this wave's 16 columns, rows 4rq .. 4rq+3
+    const int iw = c0 + 16 * wv + lr;
+    const uint32_t cbase = (uint32_t)((b * H1 + ROWS * rq) * W1 + iw) * 8u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int iw = c0 + 16 * j + lr;
-      rg.codes[j] =
-          buf_load8(rs.code1, (ih >= 0 && ih < H1 && iw < W1) ? (uint32_t)((b * H1 + ih) * W1 + iw) * 8u : BUF_OOB);
+    for (int ir = 0; ir < 4; ++ir) {
+      const bool ok = (unsigned)(ROWS * rq + ir) < (unsigned)H1 && iw < W1;
+      rg.codes[ir] = buf_load8(rs.code1, ok ? cbase + (uint32_t)(ir * W1) * 8u : BUF_OOB);
     }
   }
 }
 
-// Registers of step rq -> ring rows 4rq+2 .. 4rq+5.  Lane = (pooled pixel, 8-channel group): up to four 16-byte records.
+// Registers of step rq -> ring rows 4rq+2 .. 4rq+5.  Lane = (pooled pixel, 8-channel group): four 16-byte records.
 template <typename T, bool FUSE, bool XVEC>
-__device__ __forceinline__ void bd_expand(const BdStepRegs<T, FUSE, XVEC>& rg, int rq, T* __restrict__ dc_s) {
+__device__ __forceinline__ void bd_expand(const BdStepRegs<T, FUSE, XVEC>& rg, const BdLane<FUSE, XVEC>& ln, int rq,
+                                          T* __restrict__ dc_s) {
   constexpr int S32 = C2<T>::S32;
-  const int t = threadIdx.x;
+  const int og = threadIdx.x & 3;
 #pragma unroll
   for (int k = 0; k < BD_DCIT; ++k) {
-    const int i = t + 256 * k, item = i >> 2, og = i & 3;
-    if (item >= BD_ITEMS) continue;
-    const int prow = item / BD_NPC, pcol = item % BD_NPC;
+    const int prow = ln.dc_prow[k], pcol = ln.dc_pcol[k];
+    if (prow > 1) continue;
     const int slot = (ROWS * rq + 2 + 2 * prow) & (BD_RING - 1);       // even: slot + 1 never wraps
     const uint64_t cd = rg.cd[k];
     if constexpr (sizeof(T) == 2) {
@@ -768,7 +770,7 @@ __device__ __forceinline__ void bd_expand(const BdStepRegs<T, FUSE, XVEC>& rg, i
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
         const int sc = 2 * pcol + dx;                                         // stored column
-        const int piece = ((sc >> 2) & 3) ^ ((3 * og) & 3);                   // swizzled 16-byte slot of the record
+        const int piece = og ^ ((sc >> 1) & 2);                               // swizzled 16-byte slot of the record
         T* dst = dc_s + (slot * BD_WPX + sc) * S32 + 8 * piece;
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
@@ -831,6 +833,27 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
   rs.code1 = make_rsrc(code1, FUSE ? (uint32_t)B * H1 * W1 * 8 : 0u);
   copy_to_lds(w_s, wb, C2<T>::WB_ELEMS);
 
+  BdLane<FUSE, XVEC> ln;
+#pragma unroll
+  for (int k = 0; k < BD_DCIT; ++k) {
+    const int i = t + 256 * k, item = i >> 2, og = i & 3;
+    const bool has = item < BD_ITEMS;
+    ln.dc_prow[k] = has ? item / BD_NPC : 99;
+    ln.dc_pcol[k] = item % BD_NPC;
+    ln.dc_off[k] = (uint32_t)((item / BD_NPC) * W2 + item % BD_NPC) * 32 + 8 * og;
+  }
+  if constexpr (FUSE) {
+#pragma unroll
+    for (int k = 0; k < BdLane<FUSE, XVEC>::XIT; ++k) {
+      const int i = t + 256 * k;
+      constexpr int PER_ROW = XVEC ? BD_XCOLS / 4 : BD_XCOLS;
+      const int br = i / PER_ROW, bc = (i % PER_ROW) * (XVEC ? 4 : 1);
+      ln.x_br[k] = br < XROWS ? br : 99;
+      ln.x_bc[k] = bc;
+      ln.x_off[k] = (uint32_t)(br * W + bc) * 4u;
+    }
+  }
+
   // work item s = (image b, row segment seg, column tile ct); a segment is seg_len steps and starts with a pseudo step
   auto place = [&](int s_, int& b_, int& c0_, int& rq_first, int& rq_end) {
     const int ct = s_ % n_ctiles, sg = (s_ / n_ctiles) % nseg;
@@ -843,31 +866,42 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
   int s = blockIdx.x, b, c0, rq_first, rq_end;              // host guarantees gridDim.x <= n_strips
   place(s, b, c0, rq_first, rq_end);
   int rq = rq_first - 1;
-  bd_issue<T, FUSE, XVEC>(rg, b, c0, rq, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
+  bd_issue<T, FUSE, XVEC>(rg, ln, b, c0, rq, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
+  __syncthreads();                                          // weight image complete
+
+  // Wave w computes the 4 output rows of column tile w (16 columns).  A dc2 row fragment (one per tap column aw) feeds
+  // the up to three output rows it touches, and the weight fragments of all nine taps stay in registers for the whole
+  // kernel (bf16): 18 LDS fragment reads per 36 MFMAs.
+  bf16x8 afr[sizeof(T) == 2 ? 9 : 1];
+  int cb[3];
+  if constexpr (sizeof(T) == 2) {
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks) afr[ks] = *(const bf16x8*)&w_s[lr * KP + 32 * ks + 8 * lg];
+#pragma unroll
+    for (int aw = 0; aw < 3; ++aw) {
+      const int sc = 16 * wv + lr + aw + 1;
+      cb[aw] = sc * S32 + 8 * (lg ^ ((sc >> 1) & 2));
+    }
+  }
   STAMP(6);
   while (s < n_strips) {
-    const int ih = ROWS * rq + wv;                          // this wave's output row
     // ---- consume the prefetched registers into the LDS images of this step
-    bd_expand<T, FUSE, XVEC>(rg, rq, dc_s);
+#ifdef GDM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(3);
+#endif
+    bd_expand<T, FUSE, XVEC>(rg, ln, rq, dc_s);
     uint64_t codes[FUSE ? 4 : 1];
     if constexpr (FUSE) {
-      if constexpr (XVEC) {
 #pragma unroll
-        for (int k = 0; k < BdStepRegs<T, FUSE, XVEC>::XIT; ++k) {
-          const int i = t + 256 * k;
-          const int vc = i % (BD_XCOLS / 4), br = i / (BD_XCOLS / 4);
-          if (br < XROWS) *(f32x4*)&x_s[br * XW + 4 * vc] = rg.xv4[k];
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < BdStepRegs<T, FUSE, XVEC>::XIT; ++k) {
-          const int i = t + 256 * k;
-          const int bc = i % BD_XCOLS, br = i / BD_XCOLS;
-          if (br < XROWS) x_s[br * XW + bc] = rg.xv[k];
+      for (int k = 0; k < BdLane<FUSE, XVEC>::XIT; ++k) {
+        if (ln.x_br[k] < XROWS) {
+          if constexpr (XVEC) *(f32x4*)&x_s[ln.x_br[k] * XW + ln.x_bc[k]] = rg.xv4[k];
+          else x_s[ln.x_br[k] * XW + ln.x_bc[k]] = rg.xv[k];
         }
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) codes[j] = rg.codes[j];
+      for (int ir = 0; ir < 4; ++ir) codes[ir] = rg.codes[ir];
     }
     STAMP(7);
     __syncthreads();
@@ -884,92 +918,101 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
         rqn = rq;                                           // nothing left: re-read the current rows
       }
     }
-    bd_issue<T, FUSE, XVEC>(rg, bn, c0n, rqn, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
+    bd_issue<T, FUSE, XVEC>(rg, ln, bn, c0n, rqn, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
     STAMP(1);
 
     if (rq >= rq_first) {
-      f32x4 acc[4];
+      f32x4 acc[4];                                         // [output row of the step]
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int ir = 0; ir < 4; ++ir) acc[ir] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if constexpr (sizeof(T) == 2) {
-        // one (flipped) tap = 32 channels per k-step; the fragments of k-step ks+1 are read before the MFMAs of ks issue
-        int cb[3], ro[3];
+        // band row rr (conv row 4rq-1+rr) contributes to output row ir = rr - ah with tap row ah; the fragments of
+        // row rr+1 are read before the MFMAs of row rr issue.  Per accumulator the taps arrive in ascending order.
+        bf16x8 bb[2][3];
+        auto row_frags = [&](int rr, bf16x8 (&bx)[3]) {
+          const int ro = ((ROWS * rq - 1 + rr) & (BD_RING - 1)) * BD_WPX * S32;
 #pragma unroll
-        for (int aw = 0; aw < 3; ++aw) {
-          const int sc = lr + aw + 1;                            // + 16 j: leaves (sc >> 2) & 3 unchanged
-          cb[aw] = sc * S32 + 8 * (((sc >> 2) & 3) ^ ((3 * lg) & 3));
-        }
-#pragma unroll
-        for (int ah = 0; ah < 3; ++ah) ro[ah] = ((ih - 1 + ah) & (BD_RING - 1)) * BD_WPX * S32;
-        bf16x8 a[2], bb[2][4];
-        auto frags = [&](int ks, bf16x8& aa, bf16x8 (&bx)[4]) {
-          const int ah = ks / 3, aw = ks % 3;
-          aa = *(const bf16x8*)&w_s[lr * KP + 32 * ks + 8 * lg];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bx[j] = *(const bf16x8*)&dc_s[ro[ah] + cb[aw] + 16 * j * S32];
+          for (int aw = 0; aw < 3; ++aw) bx[aw] = *(const bf16x8*)&dc_s[ro + cb[aw]];
         };
-        frags(0, a[0], bb[0]);
+        row_frags(0, bb[0]);
 #pragma unroll
-        for (int ks = 0; ks < 9; ++ks) {
-          if (ks + 1 < 9) frags(ks + 1, a[(ks + 1) & 1], bb[(ks + 1) & 1]);
+        for (int rr = 0; rr < ROWS + 2; ++rr) {
+          if (rr + 1 < ROWS + 2) row_frags(rr + 1, bb[(rr + 1) & 1]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j] = mfma16(a[ks & 1], bb[ks & 1][j], acc[j]);
+          for (int ah = 2; ah >= 0; --ah) {
+            const int ir = rr - ah;
+            if (ir < 0 || ir >= ROWS) continue;
+#pragma unroll
+            for (int aw = 0; aw < 3; ++aw) acc[ir] = mfma16(afr[3 * ah + aw], bb[rr & 1][aw], acc[ir]);
+          }
         }
       } else {
-#pragma unroll 2
-        for (int ks = 0; ks < 72; ++ks) {
-          const int tap = ks >> 3, o = 4 * (ks & 7) + lg;
-          const int ah = tap / 3, aw = tap % 3;
-          const float a = w_s[lr * KP + 4 * ks + lg];
-          const int rbase = ((ih - 1 + ah) & (BD_RING - 1)) * BD_WPX;
+#pragma unroll 1
+        for (int rr = 0; rr < ROWS + 2; ++rr) {
+          const int ro = ((ROWS * rq - 1 + rr) & (BD_RING - 1)) * BD_WPX;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float bb = dc_s[(rbase + 16 * j + lr + aw + 1) * S32 + o];
-            acc[j] = mfma16(a, bb, acc[j]);
-          }
+          for (int aw = 0; aw < 3; ++aw)
+#pragma unroll 2
+            for (int o4 = 0; o4 < 8; ++o4) {
+              const float bb = dc_s[(ro + 16 * wv + lr + aw + 1) * S32 + 4 * o4 + lg];
+#pragma unroll
+              for (int ah = 2; ah >= 0; --ah) {
+                const int ir = rr - ah;
+                if (ir < 0 || ir >= ROWS) continue;
+                const float a = w_s[lr * KP + 4 * ((3 * ah + aw) * 8 + o4) + lg];
+                acc[ir] = mfma16(a, bb, acc[ir]);
+              }
+            }
         }
       }
       STAMP(2);
       // C layout: col (lr) = pixel, row (4*lg + r) = input channel ci
+      const int iw = c0 + 16 * wv + lr;
       if (dp1 != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int iw = c0 + 16 * j + lr;
+        for (int ir = 0; ir < 4; ++ir) {
+          const int ih = ROWS * rq + ir;
           const bool ok = ih < H1 && iw < W1;
           const uint32_t di = (uint32_t)((b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
           if constexpr (sizeof(T) == 2) {
             bf16x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[j][r];
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[ir][r];
             buf_store8(rs.dp1, ok ? di * 2u : BUF_OOB, __builtin_bit_cast(uint64_t, v));
           } else {
-            buf_store16(rs.dp1, ok ? di * 4u : BUF_OOB, acc[j]);
+            buf_store16(rs.dp1, ok ? di * 4u : BUF_OOB, acc[ir]);
           }
         }
       }
-      STAMP(3);
       if constexpr (FUSE) {
-        // x window of pixel (row wv, column cl) starts at x_s[2 wv][2 cl + 3]; position (dy, dx) moves it by dy rows and
-        // dx columns: offset = dx + 256 dy = (pos * 129) & 0x101
-        const float* xrow = x_s + 2 * wv * XW + 2 * lr + 3;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t pf = (uint32_t)codes[j] >> (8 * lg);                 // 2-bit positions of channels 4lg..4lg+3
-          const uint32_t lv = (uint32_t)(codes[j] >> 32) >> (4 * lg);         // their live bits
+        // x window of pixel (row ir, column cl = 16 wv + lr) starts at x_s[2 ir][2 cl + 3]; position (dy, dx) moves it
+        // by dy rows and dx columns: offset = dx + 256 dy = (pos * 129) & 0x101.  The 16 gathers of row ir+1 are issued
+        // before the FMAs of row ir (register double buffer).
+        const float* xcol = x_s + 2 * (16 * wv + lr) + 3;
+        float xw[2][4][4];
+        auto gather = [&](int ir, float (&xo)[4][4]) {
+          const uint32_t pf = (uint32_t)codes[ir] >> (8 * lg);                // 2-bit positions of channels 4lg..4lg+3
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const uint32_t pos = (pf >> (2 * r)) & 3u;
+            const float* xp = xcol + 2 * ir * XW + ((pos * 129u) & 0x101u);
+            xo[r][0] = xp[0]; xo[r][1] = xp[1]; xo[r][2] = xp[XW]; xo[r][3] = xp[XW + 1];
+          }
+        };
+        gather(0, xw[0]);
+#pragma unroll
+        for (int ir = 0; ir < 4; ++ir) {
+          if (ir + 1 < 4) gather(ir + 1, xw[(ir + 1) & 1]);
+          const uint32_t lv = (uint32_t)(codes[ir] >> 32) >> (4 * lg);        // live bits of channels 4lg..4lg+3
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
             const uint32_t live = (uint32_t)((int32_t)(lv << (31 - r)) >> 31);            // 0 or ~0
-            const float av = acc[j][r];      // (bit_cast straight from a vector element reads element 0)
+            const float av = acc[ir][r];     // (bit_cast straight from a vector element reads element 0)
             const float g = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, av) & live);
-            const float* xp = xrow + 32 * j + ((pos * 129u) & 0x101u);
-            a1[r][0] = fmaf(g, xp[0], a1[r][0]);
-            a1[r][1] = fmaf(g, xp[1], a1[r][1]);
-            a1[r][2] = fmaf(g, xp[XW], a1[r][2]);
-            a1[r][3] = fmaf(g, xp[XW + 1], a1[r][3]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a1[r][q] = fmaf(g, xw[ir & 1][r][q], a1[r][q]);
             bs[r] += g;
           }
-          __builtin_amdgcn_sched_barrier(0);   // keep the LDS gathers of one column tile from piling up across tiles
         }
       }
       STAMP(4);
