@@ -22,4 +22,4 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmArgs& g, int m, in
 // rows, row-major C); launches it (and the split-K reduce is left to the caller).  Defined in gemm_bf16.hip.
 bool gdm_gemm_bf16_fast_ok(const GemmArgs& g, int a_dtype, int b_dtype);
 int gdm_gemm_bf16_fast_launch(const GemmArgs& g, int a_dtype, int b_dtype, hipStream_t s);
-constexpr int GDM_GEMM_FAST_KT = 32;
+constexpr int GDM_GEMM_FAST_KT = 64;   // split-K slabs are multiples of the widest K tile
