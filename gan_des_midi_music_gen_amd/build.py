@@ -11,7 +11,11 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libgdm_hip.so")
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         # MFMA results straight into VGPRs: every kernel here post-processes its accumulators with VALU code and none
+         # needs more than 256 registers, so the AGPR form only adds v_accvgpr_read/write traffic (5-15 % of the VALU
+         # instructions of the issue-bound conv kernels)
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 FLAGS += os.environ.get("GDM_HIPCC_FLAGS", "").split()     # experiment switches (-D...), empty for the shipped build
 
 

@@ -59,74 +59,154 @@ template <typename T> struct Px;  // LDS pixel-record strides (elements) for 16-
 template <> struct Px<float> { static constexpr int S16 = 17, S32 = 33; };
 template <> struct Px<__bf16> { static constexpr int S16 = 16, S32 = 32; };
 
+// Tile staging goes through buffer descriptors: a lane that falls outside the image hands the load an offset past
+// num_records and the hardware returns zeros (stores are dropped), so halo handling needs no branch and no select.
+// Branch-free staging matters twice: the loads of a tile issue back to back, and hipcc's s_waitcnt bookkeeping stays
+// exact (with loads inside exec-masked branches it drained the whole queue -- vmcnt(0) -- right after issuing a
+// prefetch, which turned "prefetch" into "wait").  All tensors addressed this way are < 2 GiB (checked on the host).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr uint32_t BUF_OOB = 0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+  // descriptor words must be provably wave-uniform, or every buffer op gets wrapped in a waterfall loop
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0,
+                                           __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 buf_load16(rsrc_t r, uint32_t off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ uint64_t buf_load8(rsrc_t r, uint32_t off) {
+  return __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+}
+__device__ __forceinline__ float buf_load4(rsrc_t r, uint32_t off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void buf_store16(rsrc_t r, uint32_t off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+__device__ __forceinline__ void buf_store8(rsrc_t r, uint32_t off, uint64_t v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0, 0);
+}
+__device__ __forceinline__ void buf_store4(rsrc_t r, uint32_t off, uint32_t v) {
+  __builtin_amdgcn_raw_buffer_store_b32(v, r, off, 0, 0);
+}
+__device__ __forceinline__ void buf_store2(rsrc_t r, uint32_t off, uint32_t v) {
+  __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, off, 0, 0);
+}
+
 // =====================================================================================================================
 // conv1 forward: Conv2d(1,16,k2,s1,p1) + ReLU + MaxPool2d(2)
-// code1 (uint64 per pooled pixel): bits [2c+1:2c] = argmax position (dy*2+dx, first max in scan order like
-// aten::max_pool2d_with_indices), bit 32+c = channel c is live (pooled value > 0, i.e. ReLU passes gradient).
+// code1 (uint64 per pooled pixel) = four 16-bit fields, field g for channels 4g..4g+3:
+//   bits [2r+1:2r] = argmax position of channel 4g+r (dy*2+dx, first max in scan order like
+//   aten::max_pool2d_with_indices), bit 8+r = channel is live (pooled value > 0, i.e. ReLU passes gradient).
+//
+// The 2x2 stencil is a [16 channels x 4 taps] x [4 taps x pixels] product: one exact-fp32 v_mfma_f32_16x16x4_f32 per
+// pooling position and 16 pooled pixels, bias as the accumulator's initial value.  A wave takes units of 16 pooled
+// pixels of one pooled row; in the result lane (lr, lg) holds channels 4lg..4lg+3 of pixel lr for all four positions,
+// so max-pool, argmax and ReLU are in-lane and the lane stores 8/16 bytes of p1 and one 16-bit code field.  (As a VALU
+// stencil this layer cost ~10 instructions per output value and was issue-bound at 40 % of its memory roofline.)
 // =====================================================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, int B, int H, int W, int H1,
-                                                        int W1, T* __restrict__ p1, uint64_t* __restrict__ code1) {
-  const int64_t total = (int64_t)B * H1 * W1;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int pw = (int)(idx % W1);
-    const int ph = (int)((idx / W1) % H1);
-    const int b = (int)(idx / ((int64_t)W1 * H1));
-    const float* xb = x + (int64_t)b * H * W;
-    float in[3][3];
+                                                        int W1, int n_units, T* __restrict__ p1,
+                                                        uint64_t* __restrict__ code1) {
+  const int t = threadIdx.x, l = t & 63, lr = l & 15, lg = l >> 4;
+  // the wave index is uniform: keep everything derived from it in scalar registers
+  const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (t >> 6)), n_waves = gridDim.x * 4;
+  const int upr = (W1 + 15) >> 4;                            // units per pooled row
+  const rsrc_t xr = make_rsrc(x, (uint32_t)B * H * W * 4);
+  const rsrc_t pr = make_rsrc(p1, (uint32_t)B * H1 * W1 * 16 * sizeof(T));
+  const rsrc_t cr = make_rsrc(code1, (uint32_t)B * H1 * W1 * 8);
+  // A operand: lane (row = channel lr, k = tap lg); accumulator rows 4lg + r = channels
+  const float aw = w[lr * 4 + lg];
+  const f32x4 b4 = {bias[4 * lg], bias[4 * lg + 1], bias[4 * lg + 2], bias[4 * lg + 3]};
+  // B operand: lane (k = tap lg = kh*2+kw, column = pixel lr) reads x[2ph-1+kh+dy][2pw-1+kw+dx] for position (dy,dx)
+  const int r_lo = (lg >> 1) - 1, c_lo = 2 * lr + (lg & 1) - 1;
+  uint32_t loff[4];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int ih = 2 * ph - 1 + r;
+  for (int p = 0; p < 4; ++p) loff[p] = (uint32_t)(((r_lo + (p >> 1)) * W + c_lo + (p & 1)) * 4);   // may wrap: added to base
+
+  // wave w takes units w, w + n_waves, ... (all waves sweep the tensors as one front); a unit's (seg, ph, b) is
+  // carried from step to step with scalar carries, never re-divided
+  struct Pos { int seg, ph, b; };
+  const int dseg = n_waves % upr, dph = (n_waves / upr) % H1, db = n_waves / (upr * H1);
+  auto advance = [&](Pos& q) {
+    q.seg += dseg; q.ph += dph; q.b += db;
+    if (q.seg >= upr) { q.seg -= upr; ++q.ph; }
+    if (q.ph >= H1) { q.ph -= H1; ++q.b; }
+  };
+  auto load = [&](const Pos& q, float (&xv)[4]) {
+    const int b = min(q.b, B - 1);                           // past the end: re-read the last image (stores are dropped)
+    const uint32_t base = (uint32_t)(((b * H + 2 * q.ph) * W + 32 * q.seg) * 4);
+    if (q.ph > 0 && 2 * q.ph + 1 < H && q.seg > 0 && 32 * q.seg + 32 < W) {      // interior unit (scalar test)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int iw = 2 * pw - 1 + s;
-        in[r][s] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? xb[(int64_t)ih * W + iw] : 0.f;
-      }
+      for (int p = 0; p < 4; ++p) xv[p] = buf_load4(xr, base + loff[p]);
+      return;
     }
-    uint64_t code = 0;
-    T outv[16];
-    // two channels per packed-fp32 instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_max_f32): the stencil is VALU-bound
+    const int row0 = 2 * q.ph + r_lo, col0 = 32 * q.seg + c_lo;
+    const bool rok[2] = {(unsigned)row0 < (unsigned)H, (unsigned)(row0 + 1) < (unsigned)H};
+    const bool cok[2] = {(unsigned)col0 < (unsigned)W, (unsigned)(col0 + 1) < (unsigned)W};
 #pragma unroll
-    for (int cp = 0; cp < 8; ++cp) {
-      const int c = 2 * cp;
-      const f32x2 w00 = {w[c * 4 + 0], w[c * 4 + 4]}, w01 = {w[c * 4 + 1], w[c * 4 + 5]};
-      const f32x2 w10 = {w[c * 4 + 2], w[c * 4 + 6]}, w11 = {w[c * 4 + 3], w[c * 4 + 7]};
-      const f32x2 bc = {bias[c], bias[c + 1]};
-      f32x2 v[4];
+    for (int p = 0; p < 4; ++p) xv[p] = buf_load4(xr, (rok[p >> 1] && cok[p & 1]) ? base + loff[p] : BUF_OOB);
+  };
+  auto finish = [&](const Pos& q, bool valid, const float (&xv)[4]) {
+    f32x4 acc[4];
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy)
+    for (int p = 0; p < 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, xv[p], b4, 0, 0, 0);
+    uint32_t field = 0;
+    float best[4];
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-          // same accumulation order as a k-ordered dot product, bias added last (as aten's conv does)
-          f32x2 acc = (f32x2){in[dy][dx], in[dy][dx]} * w00;
-          acc = __builtin_elementwise_fma((f32x2){in[dy][dx + 1], in[dy][dx + 1]}, w01, acc);
-          acc = __builtin_elementwise_fma((f32x2){in[dy + 1][dx], in[dy + 1][dx]}, w10, acc);
-          acc = __builtin_elementwise_fma((f32x2){in[dy + 1][dx + 1], in[dy + 1][dx + 1]}, w11, acc);
-          acc += bc;
-          v[dy * 2 + dx] = __builtin_elementwise_max(acc, (f32x2){0.f, 0.f});
-        }
-      const f32x2 best2 = __builtin_elementwise_max(__builtin_elementwise_max(v[0], v[1]),
-                                                    __builtin_elementwise_max(v[2], v[3]));
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const float best = best2[e];
-        // first position (scan order) that attains the maximum == aten's strict '>' scan
-        const int bi = v[0][e] == best ? 0 : (v[1][e] == best ? 1 : (v[2][e] == best ? 2 : 3));
-        outv[c + e] = from_f32<T>(best);
-        code |= (uint64_t)bi << (2 * (c + e));
-        if (best > 0.f) code |= 1ull << (32 + c + e);
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float v0 = acc[0][r], v1 = acc[1][r], v2 = acc[2][r], v3 = acc[3][r];
+      const float m = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+      uint32_t pos = 3u;                        // select chain, last write wins = first maximum in scan order
+      pos = v2 == m ? 2u : pos;
+      pos = v1 == m ? 1u : pos;
+      pos = v0 == m ? 0u : pos;
+      best[r] = fmaxf(m, 0.f);
+      field |= pos << (2 * r);
+      field |= (m > 0.f ? 1u : 0u) << (8 + r);
     }
-    T* o = p1 + idx * 16;
+    const int pw = 16 * q.seg + lr;
+    const uint32_t pix = (uint32_t)((q.b * H1 + q.ph) * W1 + pw);
+    const bool ok = valid && pw < W1;
     if constexpr (sizeof(T) == 2) {
-      *(bf16x8*)(o) = *(bf16x8*)&outv[0];
-      *(bf16x8*)(o + 8) = *(bf16x8*)&outv[8];
-    } else {
+      bf16x4 h;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *(f32x4*)(o + 4 * q) = *(f32x4*)&outv[4 * q];
+      for (int r = 0; r < 4; ++r) h[r] = (__bf16)best[r];
+      buf_store8(pr, ok ? pix * 32u + 8u * lg : BUF_OOB, __builtin_bit_cast(uint64_t, h));
+    } else {
+      buf_store16(pr, ok ? pix * 64u + 16u * lg : BUF_OOB, (f32x4){best[0], best[1], best[2], best[3]});
     }
-    code1[idx] = code;
+    buf_store2(cr, ok ? pix * 8u + 2u * lg : BUF_OOB, field);
+  };
+  int u = wave;
+  if (u >= n_units) return;
+  // DEPTH units in flight per wave; every trip issues the same loads and stores (units past the end re-read valid
+  // memory and their stores are dropped), so the waits between them are exact counts.  The sched_barriers keep the
+  // compiler from sinking the refill loads below the next unit's MFMAs (which would expose their latency again).
+  constexpr int DEPTH = 4;
+  Pos q[DEPTH];
+  float xv[DEPTH][4];
+  q[0] = {u % upr, (u / upr) % H1, u / (upr * H1)};
+#pragma unroll
+  for (int d = 1; d < DEPTH; ++d) { q[d] = q[d - 1]; advance(q[d]); }
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load(q[d], xv[d]);
+  for (; u < n_units; u += DEPTH * n_waves) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      finish(q[d], u + d * n_waves < n_units, xv[d]);
+#pragma unroll
+      for (int e = 0; e < DEPTH; ++e) advance(q[d]);
+      load(q[d], xv[d]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 }
 
@@ -163,9 +243,10 @@ __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restri
     const T* g16 = dp1 + idx * 16;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      const bool live = (code >> (32 + c)) & 1;
+      const uint32_t field = (uint32_t)(code >> (16 * (c >> 2))) & 0xffffu;     // code1 format: see conv1_fwd_kernel
+      const bool live = (field >> (8 + (c & 3))) & 1;
       const float g = live ? to_f32(g16[c]) : 0.f;
-      const int pos = (int)((code >> (2 * c)) & 3);
+      const int pos = (int)((field >> (2 * (c & 3))) & 3);
       const bool dy = pos >> 1, dx = pos & 1;
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
@@ -289,42 +370,6 @@ template <typename T>
 __device__ __forceinline__ void copy_to_lds(T* __restrict__ dst, const T* __restrict__ src, int nelems) {
   const int chunks = nelems * (int)sizeof(T) / 16;
   for (int i = threadIdx.x; i < chunks; i += 256) ((f32x4*)dst)[i] = ((const f32x4*)src)[i];
-}
-
-// Tile staging goes through buffer descriptors: a lane that falls outside the image hands the load an offset past
-// num_records and the hardware returns zeros (stores are dropped), so halo handling needs no branch and no select.
-// Branch-free staging matters twice: the loads of a tile issue back to back, and hipcc's s_waitcnt bookkeeping stays
-// exact (with loads inside exec-masked branches it drained the whole queue -- vmcnt(0) -- right after issuing a
-// prefetch, which turned "prefetch" into "wait").  All tensors addressed this way are < 2 GiB (checked on the host).
-using rsrc_t = __amdgpu_buffer_rsrc_t;
-constexpr uint32_t BUF_OOB = 0x80000000u;
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
-  // descriptor words must be provably wave-uniform, or every buffer op gets wrapped in a waterfall loop
-  const uint64_t a = (uint64_t)p;
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
-  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-  return __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)hi << 32) | lo), 0,
-                                           __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x4 buf_load16(rsrc_t r, uint32_t off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
-}
-__device__ __forceinline__ uint64_t buf_load8(rsrc_t r, uint32_t off) {
-  return __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
-}
-__device__ __forceinline__ float buf_load4(rsrc_t r, uint32_t off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
-}
-__device__ __forceinline__ void buf_store16(rsrc_t r, uint32_t off, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
-}
-__device__ __forceinline__ void buf_store8(rsrc_t r, uint32_t off, uint64_t v) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0, 0);
-}
-__device__ __forceinline__ void buf_store4(rsrc_t r, uint32_t off, uint32_t v) {
-  __builtin_amdgcn_raw_buffer_store_b32(v, r, off, 0, 0);
 }
 
 // p1 halo band (rows r_first .. r_first+NR-1, cols c_first .. c_first+WP-1) -> LDS [row][col][S16], zero outside.
@@ -991,7 +1036,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
         const float* xcol = x_s + 2 * (16 * wv + lr) + 3;
         float xw[2][4][4];
         auto gather = [&](int ir, float (&xo)[4][4]) {
-          const uint32_t pf = (uint32_t)codes[ir] >> (8 * lg);                // 2-bit positions of channels 4lg..4lg+3
+          const uint32_t pf = (uint32_t)(codes[ir] >> (16 * lg));             // 2-bit positions of channels 4lg..4lg+3
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const uint32_t pos = (pf >> (2 * r)) & 3u;
@@ -1003,7 +1048,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
 #pragma unroll
         for (int ir = 0; ir < 4; ++ir) {
           if (ir + 1 < 4) gather(ir + 1, xw[(ir + 1) & 1]);
-          const uint32_t lv = (uint32_t)(codes[ir] >> 32) >> (4 * lg);        // live bits of channels 4lg..4lg+3
+          const uint32_t lv = (uint32_t)(codes[ir] >> (16 * lg + 8));         // live bits of channels 4lg..4lg+3
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const uint32_t live = (uint32_t)((int32_t)(lv << (31 - r)) >> 31);            // 0 or ~0
@@ -1240,11 +1285,13 @@ extern "C" int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* 
   GDM_REQUIRE(x && w && bias && p1 && code1, "gdm_simnn_conv1_fwd: null pointer");
   GDM_REQUIRE(B > 0 && H >= 1 && W >= 1 && gdm_dtype_ok(dtype), "gdm_simnn_conv1_fwd: bad arguments");
   const int H1 = (H + 1) / 2, W1 = (W + 1) / 2;
-  const int64_t total = (int64_t)B * H1 * W1;
-  int64_t blocks = (total + 255) / 256;
-  if (blocks > 65535 * 16) blocks = 65535 * 16;
+  GDM_REQUIRE((int64_t)B * H1 * W1 * 64 < ((int64_t)1 << 31) && (int64_t)B * H * W * 4 < ((int64_t)1 << 31),
+              "gdm_simnn_conv1_fwd: batch of %d %dx%d inputs exceeds 2 GiB per tensor", B, H, W);
+  const int64_t n_units = (int64_t)B * H1 * ((W1 + 15) / 16);          // 16 pooled pixels of one pooled row each
+  int64_t blocks = (n_units + 7) / 8;                                    // >= 2 units per wave, 4 waves per workgroup
+  if (blocks > 2048) blocks = 2048;                                      // persistent: 8 workgroups per CU
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                                       x, w, bias, B, H, W, H1, W1, (T*)p1, code1));
+                                       x, w, bias, B, H, W, H1, W1, (int)n_units, (T*)p1, code1));
   GDM_LAUNCH_OK("gdm_simnn_conv1_fwd");
   return GDM_OK;
 }
