@@ -343,8 +343,6 @@ template <typename T> struct C2 {
   static constexpr int S16 = Px<T>::S16, S32 = Px<T>::S32;
   static constexpr int WP = COLS + 2;
   static constexpr int IN_ELEMS = (ROWS + 2) * WP * S16;     // p1 halo band
-  static constexpr int DCH_ELEMS = (ROWS + 2) * WP * S32;    // dc2 halo band (data gradient)
-  static constexpr int DC_ELEMS = ROWS * COLS * S32;         // dc2 band without halo (weight gradient)
 };
 constexpr int XROWS = 2 * ROWS + 1;                          // input-window rows behind ROWS rows of the p1 geometry
 
@@ -418,110 +416,7 @@ __device__ __forceinline__ void p1_band_store(const P1Stage<T, NR>& st, T* __res
   }
 }
 
-// Rebuild rows [r_first, r_first+NR) x cols [c_first, c_first+NC) of the sparse full-resolution gradient
-//   dc2[r][c][o] = (code2[r/2][c/2][o] == 2*(r&1)+(c&1)) ? dp2[r/2][c/2][o] : 0
-// in LDS as [row][col][S32] records.  HALO: the band starts one row/column before an even origin (r_first, c_first odd),
-// otherwise at an even origin.  Work item = (pooled pixel, group of 8 channels): one 16-B gradient load + one 8-B code
-// load, up to four record stores.  All loads of a lane are issued before the first record is expanded (one exposed
-// memory latency per tile instead of one per item).  A lane keeps its channel group (t & 3), so it can also
-// accumulate the bias gradient in `bsum`.
-template <typename T, int NR, int NC, bool HALO> struct DcStage {
-  static constexpr int NPR = HALO ? NR / 2 + 1 : NR / 2, NPC = HALO ? NC / 2 + 1 : NC / 2;
-  static constexpr int ITERS = (NPR * NPC + 63) / 64;
-  f32x4 g[ITERS][sizeof(T) == 2 ? 1 : 2];
-  uint64_t cd[ITERS];
-};
-
-template <typename T, int NR, int NC, bool HALO>
-__device__ __forceinline__ void dc2_load(DcStage<T, NR, NC, HALO>& st, rsrc_t dp2r, rsrc_t code2r, uint32_t img_off,
-                                         int H2, int W2, int r_first, int c_first) {
-  // img_off = element (= code byte) offset of the image; out-of-image items read zeros: gradient 0 under code 0
-  using S = DcStage<T, NR, NC, HALO>;
-  const int t = threadIdx.x, og = t & 3;
-  const int pr_first = r_first >> 1, pc_first = c_first >> 1;           // arithmetic shift = floor
-#pragma unroll
-  for (int k = 0; k < S::ITERS; ++k) {
-    const int it = (t >> 2) + 64 * k;
-    const int pr = pr_first + it / S::NPC, pc = pc_first + it % S::NPC;
-    const bool ok = it < S::NPR * S::NPC && pr >= 0 && pr < H2 && pc >= 0 && pc < W2;
-    const uint32_t gi = img_off + (uint32_t)(pr * W2 + pc) * 32 + 8 * og;
-    st.cd[k] = buf_load8(code2r, ok ? gi : BUF_OOB);
-    st.g[k][0] = buf_load16(dp2r, ok ? gi * (uint32_t)sizeof(T) : BUF_OOB);
-    if constexpr (sizeof(T) == 4) st.g[k][1] = buf_load16(dp2r, ok ? gi * 4u + 16u : BUF_OOB);
-  }
-}
-
 typedef short s16x2 __attribute__((ext_vector_type(2)));
-
-template <typename T, int NR, int NC, bool HALO, bool WITH_BSUM>
-__device__ __forceinline__ void dc2_expand(const DcStage<T, NR, NC, HALO>& st, int r_first, int c_first,
-                                           T* __restrict__ dc_s, float* bsum) {
-  using S = DcStage<T, NR, NC, HALO>;
-  constexpr int S32 = C2<T>::S32;
-  const int t = threadIdx.x, og = t & 3;
-  const int pr_first = r_first >> 1, pc_first = c_first >> 1;
-#pragma unroll
-  for (int k = 0; k < S::ITERS; ++k) {
-    const int it = (t >> 2) + 64 * k;
-    if (it >= S::NPR * S::NPC) continue;
-    const int pr = pr_first + it / S::NPC, pc = pc_first + it % S::NPC;
-    const uint64_t cd = st.cd[k];
-    if constexpr (sizeof(T) == 2) {
-      // Packed 16-bit arithmetic on (code, gradient) pairs, two channels per VGPR: the gradient words stay bf16 and
-      // the selection is an AND with a 0xffff/0 lane mask  ((code ^ pos) - 1) >> 15  -- 4 VALU per pair and position
-      // instead of a byte extract, a compare, a select and two conversions per channel and position.
-      const uint32_t clo = (uint32_t)cd, chi = (uint32_t)(cd >> 32);
-      uint32_t c16[4], gw[4];
-      c16[0] = __builtin_amdgcn_perm(0u, clo, 0x0c010c00u);     // {code0, code1} in the two 16-bit lanes
-      c16[1] = __builtin_amdgcn_perm(0u, clo, 0x0c030c02u);
-      c16[2] = __builtin_amdgcn_perm(0u, chi, 0x0c010c00u);
-      c16[3] = __builtin_amdgcn_perm(0u, chi, 0x0c030c02u);
-      const u32x4 gv = __builtin_bit_cast(u32x4, st.g[k][0]);
-#pragma unroll
-      for (int w = 0; w < 4; ++w) gw[w] = gv[w];
-      if (WITH_BSUM) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const s16x2 lv = (__builtin_bit_cast(s16x2, c16[w]) - (s16x2){4, 4}) >> 15;     // code < 4: channel is live
-          const uint32_t g = gw[w] & __builtin_bit_cast(uint32_t, lv);
-          bsum[2 * w] += __builtin_bit_cast(float, g << 16);
-          bsum[2 * w + 1] += __builtin_bit_cast(float, g & 0xffff0000u);
-        }
-      }
-#pragma unroll
-      for (int pos = 0; pos < 4; ++pos) {
-        const int rl = 2 * pr + (pos >> 1) - r_first, cl = 2 * pc + (pos & 1) - c_first;
-        if (rl >= 0 && rl < NR && cl >= 0 && cl < NC) {
-          u32x4 v;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            const s16x2 tq = __builtin_bit_cast(s16x2, c16[w] ^ (0x00010001u * (uint32_t)pos));
-            const s16x2 m = (tq - (s16x2){1, 1}) >> 15;
-            v[w] = gw[w] & __builtin_bit_cast(uint32_t, m);
-          }
-          *(u32x4*)(dc_s + (rl * NC + cl) * S32 + 8 * og) = v;
-        }
-      }
-    } else {
-      float g[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { g[e] = st.g[k][0][e]; g[4 + e] = st.g[k][1][e]; }
-      if (WITH_BSUM) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bsum[e] += (((cd >> (8 * e)) & 0xff) < 4) ? g[e] : 0.f;
-      }
-#pragma unroll
-      for (int pos = 0; pos < 4; ++pos) {
-        const int rl = 2 * pr + (pos >> 1) - r_first, cl = 2 * pc + (pos & 1) - c_first;
-        if (rl >= 0 && rl < NR && cl >= 0 && cl < NC) {
-          T* dst = dc_s + (rl * NC + cl) * S32 + 8 * og;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) dst[e] = (int)((cd >> (8 * e)) & 0xff) == pos ? g[e] : 0.f;
-        }
-      }
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------- conv2 forward
 // One tile (4 conv rows x 64 columns of image b) from the LDS band in_s: MFMA implicit GEMM + bias/ReLU/pool epilogue.
@@ -1088,27 +983,43 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
 
 // -------------------------------------------------------------------------------------- conv2 backward (weights)
 // dW2[o][ci][kh][kw] = sum_{b,r,c} dc2[r][c][o] * p1[r-1+kh][c-1+kw][ci];  db2[o] = sum dc2
-// GEMM with M = 32 (o), N = 9 taps x 16 ci, K = pixels.  A workgroup walks units (image, row quad, column
-// super-tile); per unit it stages dc2 rows (4 x 128 x 32) and the p1 halo band (6 x 130 x 16) in LDS as
-// [pixel][channel] and each wave contracts its 32-column slice: bf16 reads both operands with the transposing
-// ds_read_b64_tr_b16 (the contraction index is the pixel, the LDS images are channel-contiguous).
-// Accumulators (2 x 9 tiles per wave) live in registers across all units, then waves are summed through LDS in fixed
+// GEMM with M = 32 (o), N = 9 taps x 16 ci, K = pixels.  Like the data-gradient kernel, a persistent workgroup walks
+// strips (image, 64-column tile) top to bottom in steps of 4 conv rows; wave w contracts row w of the step.  p1 lives
+// in an 8-row LDS ring (a step needs rows 4rq-1 .. 4rq+4, only 4rq+1 .. 4rq+4 are new), dc2 rows are rebuilt per step
+// from the two pooled rows they come from; the next step's rows are fetched into registers during the MFMAs.  bf16
+// reads both operands with the transposing ds_read_b64_tr_b16 (the contraction index is the pixel, the LDS images are
+// channel-contiguous); both images are swizzled by the column's bit 3 -- a half-wave's tr16 read touches columns
+// {c..c+3} and {c+8..c+11}, which without it fall on the same banks (with it: none left, checked exhaustively).
+// Accumulators (2 x 9 tiles per wave) live in registers across all steps, then waves are summed through LDS in fixed
 // order and the workgroup writes one slab.
 __device__ __forceinline__ bf16x4 lds_tr16(const __bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
 }
 
+constexpr int BW_RING = 8;                    // p1 rows in the LDS ring
+constexpr int BW_WPX = 72;                    // p1 columns per ring row (band columns 0..65, padded to a multiple of 8)
+template <typename T> struct BW {
+  static constexpr int P_ELEMS = BW_RING * BW_WPX * C2<T>::S16;
+  static constexpr int DC_ELEMS = ROWS * COLS * C2<T>::S32;
+  static constexpr int P1IT = 3;              // 16-byte chunks of the 4 new rows: 2 x 256 (columns c0..c0+63) + halo
+  // column swizzles (bf16 only): band column c of the p1 ring, 16-byte channel group og of dc2 column c
+  static __device__ __forceinline__ int pcol(int c) { return sizeof(T) == 2 ? (c ^ (4 * ((c >> 3) & 1))) : c; }
+  static __device__ __forceinline__ int dcpiece(int og, int c) { return sizeof(T) == 2 ? (og ^ (2 * ((c >> 3) & 1))) : og; }
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restrict__ dp2,
                                                                const uint8_t* __restrict__ code2,
                                                                const T* __restrict__ p1, int B, int H1, int W1,
-                                                               int H2, int W2, int n_ctiles, int n_units,
-                                                               float* __restrict__ slabs) {
-  constexpr int S16 = C2<T>::S16, S32 = C2<T>::S32, WP = C2<T>::WP;
+                                                               int H2, int W2, int n_ctiles, int nseg, int seg_len,
+                                                               int n_items, float* __restrict__ slabs) {
+  constexpr int S16 = C2<T>::S16, S32 = C2<T>::S32, WPX = BW_WPX;
+  constexpr int PIECES = 2, EPP = 8;          // a p1 pixel record is staged as two 8-channel halves (16 B bf16, 32 B fp32)
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   T* dc_s = (T*)dyn_smem;
-  T* p_s = dc_s + C2<T>::DC_ELEMS;
+  T* p_s = dc_s + BW<T>::DC_ELEMS;
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
+  const int nrq = (H1 + ROWS - 1) / ROWS, G = gridDim.x;
   f32x4 acc[2][9];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1117,74 +1028,219 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
   float bsum[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
-  const int nrq = (H1 + ROWS - 1) / ROWS;
 
   const rsrc_t dp2r = make_rsrc(dp2, (uint32_t)B * H2 * W2 * 32 * sizeof(T));
   const rsrc_t code2r = make_rsrc(code2, (uint32_t)B * H2 * W2 * 32);
   const rsrc_t p1r = make_rsrc(p1, (uint32_t)B * H1 * W1 * 16 * sizeof(T));
-  DcStage<T, ROWS, COLS, false> st;
-  P1Stage<T, ROWS + 2> sp;
-  auto issue = [&](int v) {
-    const int ct = v % n_ctiles, rq = (v / n_ctiles) % nrq, b = v / (n_ctiles * nrq);
-    dc2_load(st, dp2r, code2r, (uint32_t)b * H2 * W2 * 32, H2, W2, ROWS * rq, ct * COLS);
-    p1_band_load(sp, p1r, (uint32_t)b * H1 * W1 * 16 * sizeof(T), H1, W1, ROWS * rq - 1, ct * COLS - 1);
-  };
-  const int G = gridDim.x;
-  int u = blockIdx.x;                                       // host guarantees gridDim.x <= n_units
-  issue(u);
-  for (; u < n_units; u += G) {
-    const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq;
-    const int c0 = ct * COLS;
-    dc2_expand<T, ROWS, COLS, false, true>(st, ROWS * rq, c0, dc_s, bsum);
-    p1_band_store(sp, p_s);
-    __syncthreads();
-    issue(u + G < n_units ? u + G : u);    // next unit's loads fly under this unit's MFMAs (always issued: no branch)
-    // wave wv contracts row wv of the unit (64 pixels = 2 bf16 k-steps / 16 fp32 k-steps)
-    const int d = wv;
-    if constexpr (sizeof(T) == 2) {
-      const int q = lr >> 2, p = lr & 3;
+
+  // ---- per-lane staging constants
+  // dc2: lane = (pooled pixel item = t >> 2 of the 2 x 32 pooled block, 8-channel group og)
+  const int og = t & 3, dprow = (t >> 2) >> 5, dpcol = (t >> 2) & 31;
+  const uint32_t dc_goff = (uint32_t)(dprow * W2 + dpcol) * 32 + 8 * og;
+  // p1: chunk k -> (new row 0..3, band column 0..65, piece); chunks 0..511 cover band columns 1..64, 512..527 the halo
+  int pr_row[BW<T>::P1IT], pr_col[BW<T>::P1IT], pr_lds[BW<T>::P1IT];
+  uint32_t pr_goff[BW<T>::P1IT];
 #pragma unroll
-      for (int sgm = 0; sgm < COLS / 32; ++sgm) {
-        const int cb = 32 * sgm + 8 * lg;   // this lane group's 8 pixels: cols cb .. cb+7 of row d
-        bf16x8 a[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const bf16x4 lo = lds_tr16(&dc_s[(d * COLS + cb + q) * S32 + 16 * i + 4 * p]);
-          const bf16x4 hi = lds_tr16(&dc_s[(d * COLS + cb + 4 + q) * S32 + 16 * i + 4 * p]);
-          a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-        bf16x8 bb[2];
-        auto bfrag = [&](int tap) {
-          const int kh = tap / 3, kw = tap % 3;
-          const bf16x4 lo = lds_tr16(&p_s[((d + kh) * WP + cb + kw + q) * S16 + 4 * p]);
-          const bf16x4 hi = lds_tr16(&p_s[((d + kh) * WP + cb + kw + 4 + q) * S16 + 4 * p]);
-          return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        };
-        bb[0] = bfrag(0);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {      // the next tap's fragment is read before this tap's MFMAs issue
-          if (tap + 1 < 9) bb[(tap + 1) & 1] = bfrag(tap + 1);
-#pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i][tap] = mfma16(a[i], bb[tap & 1], acc[i][tap]);
-        }
-      }
+  for (int k = 0; k < BW<T>::P1IT; ++k) {
+    const int i = t + 256 * k;
+    int row, col, piece;
+    if (k < 2) {                                  // 4 rows x 64 columns x 2 halves = 512 chunks
+      piece = i % PIECES; col = 1 + (i / PIECES) % 64; row = i / (PIECES * 64);
     } else {
-#pragma unroll 2
-      for (int ks = 0; ks < COLS / 4; ++ks) {
-        const int cpix = 4 * ks + lg;
-        float a[2];
+      const int j = i - 512;                      // halo columns 0 and 65
+      piece = j % PIECES; col = ((j / PIECES) & 1) ? 65 : 0; row = j / (2 * PIECES);
+    }
+    const bool has = row < 4;
+    pr_row[k] = has ? row : 99;
+    pr_col[k] = col;
+    pr_goff[k] = (uint32_t)((row * W1 + col) * 16 + piece * EPP) * (uint32_t)sizeof(T);
+    pr_lds[k] = BW<T>::pcol(col) * S16 + piece * EPP;       // + slot * WPX * S16
+  }
+
+  struct Regs {
+    f32x4 g[sizeof(T) == 2 ? 1 : 2];
+    uint64_t cd;
+    f32x4 p[(sizeof(T) == 2 ? 1 : 2) * BW<T>::P1IT];
+  } rg;
+  auto issue = [&](int b, int c0, int rq, bool with_dc) {
+    {   // dc2: pooled rows 2rq, 2rq+1, pooled columns c0/2 .. c0/2+31
+      const int pr = 2 * rq + dprow, pc = (c0 >> 1) + dpcol;
+      const bool ok = with_dc && pr >= 0 && pr < H2 && pc < W2;
+      const uint32_t gi = (uint32_t)b * H2 * W2 * 32 + (uint32_t)(2 * rq * W2 + (c0 >> 1)) * 32 + dc_goff;
+      rg.cd = buf_load8(code2r, ok ? gi : BUF_OOB);
+      rg.g[0] = buf_load16(dp2r, ok ? gi * (uint32_t)sizeof(T) : BUF_OOB);
+      if constexpr (sizeof(T) == 4) rg.g[1] = buf_load16(dp2r, ok ? gi * 4u + 16u : BUF_OOB);
+    }
+    // p1: rows 4rq+1 .. 4rq+4, band columns 0..65 = image columns c0-1 .. c0+64
+    const int r0 = ROWS * rq + 1, cc0 = c0 - 1;
+    const uint32_t base = (uint32_t)((b * H1 + r0) * W1 + cc0) * 16 * (uint32_t)sizeof(T);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = dc_s[(d * COLS + cpix) * S32 + 16 * i + lr];
+    for (int k = 0; k < BW<T>::P1IT; ++k) {
+      const bool ok = (unsigned)(r0 + pr_row[k]) < (unsigned)H1 && (unsigned)(cc0 + pr_col[k]) < (unsigned)W1;
+      rg.p[k] = buf_load16(p1r, ok ? base + pr_goff[k] : BUF_OOB);
+      if constexpr (sizeof(T) == 4) {
+        // fp32: a half record is 32 bytes -> second 16 bytes
+        rg.p[BW<T>::P1IT + k] = buf_load16(p1r, ok ? base + pr_goff[k] + 16u : BUF_OOB);
+      }
+    }
+  };
+
+  auto place = [&](int s_, int& b_, int& c0_, int& rq_first, int& rq_end) {
+    const int ct = s_ % n_ctiles, sg = (s_ / n_ctiles) % nseg;
+    b_ = s_ / (n_ctiles * nseg);
+    c0_ = ct * COLS;
+    rq_first = sg * seg_len;
+    rq_end = min(rq_first + seg_len, nrq);
+  };
+  int s = blockIdx.x, b, c0, rq_first, rq_end;            // host guarantees gridDim.x <= n_items
+  place(s, b, c0, rq_first, rq_end);
+  int rq = rq_first - 1;                                   // pseudo step: brings in p1 rows 4 rq_first - 1 and 4 rq_first
+  issue(b, c0, rq, false);
+
+  // per-lane fragment addresses that never change: swizzled p1 band columns for (segment, kw, lo/hi)
+  int pcol_off[2][3][2];
+  const int q = lr >> 2, p4 = lr & 3;
+  if constexpr (sizeof(T) == 2) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int kh = tap / 3, kw = tap % 3;
-          const float bb = p_s[((d + kh) * WP + cpix + kw) * S16 + lr];
+    for (int sg2 = 0; sg2 < 2; ++sg2)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i][tap] = mfma16(a[i], bb, acc[i][tap]);
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi)
+          pcol_off[sg2][kw][hi] = BW<T>::pcol(32 * sg2 + 8 * lg + kw + q + 4 * hi) * S16 + 4 * p4;
+  }
+
+  while (s < n_items) {
+    // ---- registers -> LDS: dc2 rows of this step, p1 ring rows 4rq+1 .. 4rq+4
+    if (rq >= rq_first) {
+      const uint64_t cd = rg.cd;
+      if constexpr (sizeof(T) == 2) {
+        const uint32_t clo = (uint32_t)cd, chi = (uint32_t)(cd >> 32);
+        uint32_t c16[4], gw[4];
+        c16[0] = __builtin_amdgcn_perm(0u, clo, 0x0c010c00u);
+        c16[1] = __builtin_amdgcn_perm(0u, clo, 0x0c030c02u);
+        c16[2] = __builtin_amdgcn_perm(0u, chi, 0x0c010c00u);
+        c16[3] = __builtin_amdgcn_perm(0u, chi, 0x0c030c02u);
+        const u32x4 gv = __builtin_bit_cast(u32x4, rg.g[0]);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) gw[w] = gv[w];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {                        // bias gradient: channels whose pooled value was live
+          const s16x2 lv = (__builtin_bit_cast(s16x2, c16[w]) - (s16x2){4, 4}) >> 15;
+          const uint32_t g = gw[w] & __builtin_bit_cast(uint32_t, lv);
+          bsum[2 * w] += __builtin_bit_cast(float, g << 16);
+          bsum[2 * w + 1] += __builtin_bit_cast(float, g & 0xffff0000u);
+        }
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int col = 2 * dpcol + dx;
+          T* dst = dc_s + (2 * dprow * COLS + col) * S32 + 8 * BW<T>::dcpiece(og, col);
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy) {
+            const uint32_t pos = 2 * dy + dx;
+            u32x4 v;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const s16x2 tq = __builtin_bit_cast(s16x2, c16[w] ^ (0x00010001u * pos));
+              const s16x2 m = (tq - (s16x2){1, 1}) >> 15;
+              v[w] = gw[w] & __builtin_bit_cast(uint32_t, m);
+            }
+            *(u32x4*)(dst + dy * COLS * S32) = v;
+          }
+        }
+      } else {
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[e] = rg.g[0][e]; g[4 + e] = rg.g[1][e]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += (((cd >> (8 * e)) & 0xff) < 4) ? g[e] : 0.f;
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+          T* dst = dc_s + ((2 * dprow + (pos >> 1)) * COLS + 2 * dpcol + (pos & 1)) * S32 + 8 * og;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dst[e] = (int)((cd >> (8 * e)) & 0xff) == pos ? g[e] : 0.f;
         }
       }
     }
-    __syncthreads();   // this unit's readers are done: the LDS images may be rebuilt
+#pragma unroll
+    for (int k = 0; k < BW<T>::P1IT; ++k) {
+      if (pr_row[k] > 3) continue;
+      const int slot = (ROWS * rq + 1 + pr_row[k]) & (BW_RING - 1);
+      T* dst = p_s + slot * WPX * S16 + pr_lds[k];
+      if constexpr (sizeof(T) == 2) {
+        *(f32x4*)dst = rg.p[k];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dst[e] = rg.p[k][e]; dst[4 + e] = rg.p[BW<T>::P1IT + k][e]; }
+      }
+    }
+    __syncthreads();
+    // ---- next step's loads (always issued: the very last step re-reads its own rows)
+    int sn = s, bn = b, c0n = c0, rqn = rq + 1, rq_first_n = rq_first, rq_end_n = rq_end;
+    if (rqn == rq_end) {
+      sn = s + G;
+      if (sn < n_items) {
+        place(sn, bn, c0n, rq_first_n, rq_end_n);
+        rqn = rq_first_n - 1;
+      } else {
+        rqn = rq;
+      }
+    }
+    issue(bn, c0n, rqn, rqn >= rq_first_n);
+
+    if (rq >= rq_first) {
+      // wave wv contracts row wv of the step (64 pixels = 2 bf16 k-steps / 16 fp32 k-steps)
+      const int d = wv;
+      if constexpr (sizeof(T) == 2) {
+        int prow[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) prow[kh] = ((ROWS * rq + d - 1 + kh) & (BW_RING - 1)) * WPX * S16;
+#pragma unroll
+        for (int sgm = 0; sgm < COLS / 32; ++sgm) {
+          const int cb = 32 * sgm + 8 * lg;   // this lane group's 8 pixels: cols cb .. cb+7 of row d
+          bf16x8 a[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int pc8 = 16 * (i ^ (lg & 1)) + 4 * p4;     // swizzled 8-byte piece (columns cb+q, cb+4+q share bit 3)
+            const bf16x4 lo = lds_tr16(&dc_s[(d * COLS + cb + q) * S32 + pc8]);
+            const bf16x4 hi = lds_tr16(&dc_s[(d * COLS + cb + 4 + q) * S32 + pc8]);
+            a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+          bf16x8 bb[2];
+          auto bfrag = [&](int tap) {
+            const int kh = tap / 3, kw = tap % 3;
+            const bf16x4 lo = lds_tr16(&p_s[prow[kh] + pcol_off[sgm][kw][0]]);
+            const bf16x4 hi = lds_tr16(&p_s[prow[kh] + pcol_off[sgm][kw][1]]);
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          };
+          bb[0] = bfrag(0);
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {      // the next tap's fragment is read before this tap's MFMAs issue
+            if (tap + 1 < 9) bb[(tap + 1) & 1] = bfrag(tap + 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][tap] = mfma16(a[i], bb[tap & 1], acc[i][tap]);
+          }
+        }
+      } else {
+#pragma unroll 2
+        for (int ks = 0; ks < COLS / 4; ++ks) {
+          const int cpix = 4 * ks + lg;
+          float a[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a[i] = dc_s[(d * COLS + cpix) * S32 + 16 * i + lr];
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap % 3;
+            const int slot = (ROWS * rq + d - 1 + kh) & (BW_RING - 1);
+            const float bb = p_s[(slot * WPX + cpix + kw) * S16 + lr];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][tap] = mfma16(a[i], bb, acc[i][tap]);
+          }
+        }
+      }
+    }
+    __syncthreads();   // this step's readers are done: the LDS images may be rebuilt
+    s = sn; b = bn; c0 = c0n; rq = rqn; rq_first = rq_first_n; rq_end = rq_end_n;
   }
   // ---- cross-wave reduction in fixed order (wave 0 stores, waves 1..3 add in turn: each element is touched by the
   //      same lane position in every wave) and slab write.  slab layout: [o 32][tap 9][ci 16] then 32 bias sums.
@@ -1236,8 +1292,6 @@ inline int conv1_slabs(int64_t total) {
   int64_t b = (total + 256 * 8 - 1) / (256 * 8);
   return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
-inline int conv2w_blocks(int n_units) { return n_units < 1024 ? n_units : 1024; }
-
 // conv2 backward-data work decomposition: items = (image, row segment, 64-column tile).  Whole-height strips when
 // they fill the chip (2 resident workgroups per CU x 256 CUs); small batches are cut into row segments (each pays one
 // pseudo step).  A pure function of the shapes: the slab count of the fused variant must be reproducible by _finish.
@@ -1255,6 +1309,21 @@ inline BdPlan bd_plan(int B, int H1, int W1, bool fuse) {
   p.n_items = (int)(strips * p.nseg);
   const int cap = fuse ? 512 : 768;
   p.blocks = p.n_items < cap ? p.n_items : cap;
+  return p;
+}
+// conv2 backward-weight: same items, up to 4 resident workgroups per CU, small batches cut finer
+inline BdPlan bw_plan(int B, int H1, int W1) {
+  BdPlan p;
+  const int nrq = (H1 + ROWS - 1) / ROWS;
+  p.n_ctiles = (W1 + COLS - 1) / COLS;
+  const int64_t strips = (int64_t)B * p.n_ctiles;
+  int nseg = (int)((1024 + strips - 1) / strips);
+  const int max_seg = nrq / 2 > 1 ? nrq / 2 : 1;
+  nseg = nseg < 1 ? 1 : (nseg > max_seg ? max_seg : nseg);
+  p.seg_len = (nrq + nseg - 1) / nseg;
+  p.nseg = (nrq + p.seg_len - 1) / p.seg_len;
+  p.n_items = (int)(strips * p.nseg);
+  p.blocks = p.n_items < 1024 ? p.n_items : 1024;
   return p;
 }
 
@@ -1449,8 +1518,7 @@ extern "C" int gdm_simnn_conv2_bwd_fused_finish(int B, int H1, int W1, float* dw
 }
 
 extern "C" size_t gdm_simnn_conv2_bwd_weight_workspace_bytes(int B, int H1, int W1) {
-  const int n_units = B * ((H1 + ROWS - 1) / ROWS) * ((W1 + COLS - 1) / COLS);
-  return (size_t)(conv2w_blocks(n_units) + 65) * (4608 + 32) * sizeof(float);
+  return (size_t)(bw_plan(B, H1, W1).blocks + 65) * (4608 + 32) * sizeof(float);
 }
 
 extern "C" int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2, const void* p1, int B, int H1, int W1,
@@ -1464,23 +1532,24 @@ extern "C" int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2,
     return GDM_EWORKSPACE;
   }
   const int H2 = H1 / 2, W2 = W1 / 2;
-  const int n_ctiles = (W1 + COLS - 1) / COLS;
-  const int n_units = B * ((H1 + ROWS - 1) / ROWS) * n_ctiles;
-  const int nblocks = conv2w_blocks(n_units);
+  const BdPlan pl = bw_plan(B, H1, W1);
+  const int nblocks = pl.blocks;
   hipStream_t s = (hipStream_t)stream;
-  const size_t red_bytes = (size_t)4608 * sizeof(float);
+  const size_t red_bytes = (size_t)(4608 + 2048) * sizeof(float);
   if (dtype == GDM_BF16) {
-    size_t sm = (size_t)(C2<__bf16>::DC_ELEMS + C2<__bf16>::IN_ELEMS) * 2;
+    size_t sm = (size_t)(BW<__bf16>::DC_ELEMS + BW<__bf16>::P_ELEMS) * 2;
     if (sm < red_bytes) sm = red_bytes;
     allow_lds(conv2_bwd_weight_kernel<__bf16>, sm);
     hipLaunchKernelGGL(conv2_bwd_weight_kernel<__bf16>, dim3(nblocks), dim3(256), sm, s, (const __bf16*)dp2, code2,
-                       (const __bf16*)p1, B, H1, W1, H2, W2, n_ctiles, n_units, (float*)workspace);
+                       (const __bf16*)p1, B, H1, W1, H2, W2, pl.n_ctiles, pl.nseg, pl.seg_len, pl.n_items,
+                       (float*)workspace);
   } else {
-    size_t sm = (size_t)(C2<float>::DC_ELEMS + C2<float>::IN_ELEMS) * 4;
+    size_t sm = (size_t)(BW<float>::DC_ELEMS + BW<float>::P_ELEMS) * 4;
     if (sm < red_bytes) sm = red_bytes;
     allow_lds(conv2_bwd_weight_kernel<float>, sm);
     hipLaunchKernelGGL(conv2_bwd_weight_kernel<float>, dim3(nblocks), dim3(256), sm, s, (const float*)dp2, code2,
-                       (const float*)p1, B, H1, W1, H2, W2, n_ctiles, n_units, (float*)workspace);
+                       (const float*)p1, B, H1, W1, H2, W2, pl.n_ctiles, pl.nseg, pl.seg_len, pl.n_items,
+                       (float*)workspace);
   }
   float* scratch = (float*)workspace + (size_t)nblocks * (4608 + 32);
   float* sums = scratch + (size_t)64 * (4608 + 32);

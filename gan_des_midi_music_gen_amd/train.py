@@ -211,15 +211,21 @@ class SimnnTrainer(_TrainerBase):
         main = torch.cuda.current_stream()
         side = self._streams(real.device) if self.overlap else None
         keep = []
-        # --- generator forward (SIMNN.py:293-296); its output only feeds the (external) bridge -> own stream
         ws, bns = self._gen_state()
-        if side:
-            side[0].wait_stream(main)
-        with torch.cuda.stream(side[0] if side else main):
-            generated, gsaved = Fn.simnn_gen_forward(noise, ws, bns, self.gen.training, dt)
-            keep.append(gsaved)
-        self.last_generated = generated
-        if callable(fake):
+
+        def generator_forward():
+            # SIMNN.py:293-296; the output only feeds the (external) bridge -> own stream
+            if side:
+                side[0].wait_stream(main)
+            with torch.cuda.stream(side[0] if side else main):
+                generated, gsaved = Fn.simnn_gen_forward(noise, ws, bns, self.gen.training, dt)
+                keep.append(gsaved)
+            self.last_generated = generated
+            return generated
+
+        bridge = callable(fake)
+        if bridge:
+            generated = generator_forward()
             if side:
                 main.wait_stream(side[0])
             fake = fake(generated)
@@ -234,6 +240,11 @@ class SimnnTrainer(_TrainerBase):
         p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=real.device)
         code1 = torch.empty((2 * b, h1, w1s), dtype=torch.int64, device=real.device)
         ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
+        if not bridge:
+            # tensor stand-in for the bridge: the generator is independent of the discriminator step and runs beside
+            # it.  Forked after the first main-stream launch: a branch that forks at the very root of a captured graph
+            # was observed to run BEFORE the main branch instead of beside it.
+            generator_forward()
         ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
         hid, saved = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1, code1))
         # fc2 + sigmoid + both BCE terms (labels 0.9 / 0.1, SIMNN.py:284-311) + head backward: one launch pair
