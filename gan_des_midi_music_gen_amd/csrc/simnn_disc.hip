@@ -272,13 +272,18 @@ __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restri
 }
 
 // =====================================================================================================================
-// Fixed-order two-level sum of `nslabs` slabs of `width` floats (deterministic replacement for float atomics).
-// Level 1: grid (width/64, groups): a 1024-thread workgroup owns 64 consecutive elements of one slab group; wave w adds
-// slabs w, w+16, ... of its group (coalesced 256-B rows), the 16 partials are added in wave order.  Level 2 adds the
-// group partials in order.
+// Fixed-order sum of `nslabs` slabs of `width` floats (deterministic replacement for float atomics), with the
+// gradient's final placement fused into the last level.
+// A 1024-thread workgroup owns 64 consecutive elements of one slab group; wave w adds slabs w, w+16, ... of its group
+// (coalesced 256-B rows), the 16 partials are added in wave order.  Wide slabs (conv2's 4640 floats x up to 1024 slabs)
+// take two levels (groups of <= 256 slabs, then the group partials in order); 80-float slabs take one launch.
+// SINK: 0 = out[group][i];  1 = conv1 gradients (dw[64], db[16], optional accumulate);  2 = conv2 gradients
+// (slab order [o 32][tap 9][ci 16] -> dw[o][ci][tap], then db[32]).
 // =====================================================================================================================
+template <int SINK>
 __global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict__ slabs, int nslabs, int per_group,
-                                                        int width, float* __restrict__ out) {
+                                                        int width, float* __restrict__ out, float* __restrict__ dw,
+                                                        float* __restrict__ db, int accumulate) {
   __shared__ float part[16][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
@@ -298,33 +303,43 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict_
     float t = part[0][lane];
 #pragma unroll
     for (int w = 1; w < 16; ++w) t += part[w][lane];
-    out[(int64_t)blockIdx.y * width + i] = t;
+    if constexpr (SINK == 0) {
+      out[(int64_t)blockIdx.y * width + i] = t;
+    } else if constexpr (SINK == 1) {
+      float* dst = i < 64 ? dw + i : db + (i - 64);
+      *dst = accumulate ? *dst + t : t;
+    } else {
+      if (i < 4608) {
+        const int ci = i & 15, tap = (i >> 4) % 9, o = i / 144;
+        dw[(o * 16 + ci) * 9 + tap] = t;
+      } else {
+        db[i - 4608] = t;
+      }
+    }
   }
 }
 
-// sums `nslabs` slabs into `result` (width floats) using `scratch` (>= slab_groups(nslabs) * width floats)
-inline int slab_groups(int nslabs) { return nslabs <= 64 ? 1 : (nslabs + 255) / 256 > 64 ? 64 : (nslabs + 255) / 256; }
-inline void launch_slab_sum(const float* slabs, int nslabs, int width, float* scratch, float* result, hipStream_t s) {
-  const int groups = slab_groups(nslabs);
+// sums `nslabs` slabs into their sink using `scratch` (>= slab_groups(nslabs, width) * width floats)
+inline int slab_groups(int nslabs, int width) {
+  if (width <= 128 || nslabs <= 64) return 1;
+  const int g = (nslabs + 255) / 256;
+  return g > 64 ? 64 : g;
+}
+template <int SINK>
+inline void launch_slab_sum(const float* slabs, int nslabs, int width, float* scratch, float* dw, float* db,
+                            int accumulate, hipStream_t s) {
+  const int groups = slab_groups(nslabs, width);
   const int per = (nslabs + groups - 1) / groups;
   const unsigned gx = (unsigned)((width + 63) / 64);
   if (groups == 1) {
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(gx, 1), dim3(1024), 0, s, slabs, nslabs, per, width, result);
+    hipLaunchKernelGGL(slab_sum_kernel<SINK>, dim3(gx, 1), dim3(1024), 0, s, slabs, nslabs, per, width, (float*)nullptr,
+                       dw, db, accumulate);
   } else {
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(gx, groups), dim3(1024), 0, s, slabs, nslabs, per, width, scratch);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(gx, 1), dim3(1024), 0, s, (const float*)scratch, groups, groups, width,
-                       result);
+    hipLaunchKernelGGL(slab_sum_kernel<0>, dim3(gx, groups), dim3(1024), 0, s, slabs, nslabs, per, width, scratch,
+                       (float*)nullptr, (float*)nullptr, 0);
+    hipLaunchKernelGGL(slab_sum_kernel<SINK>, dim3(gx, 1), dim3(1024), 0, s, (const float*)scratch, groups, groups, width,
+                       (float*)nullptr, dw, db, accumulate);
   }
-}
-
-__global__ __launch_bounds__(128) void conv1_bwd_weight_final(const float* __restrict__ sums,
-                                                              float* __restrict__ dw, float* __restrict__ db,
-                                                              int accumulate) {
-  const int i = threadIdx.x;
-  if (i >= 80) return;
-  const float s = sums[i];
-  float* dst = i < 64 ? dw + i : db + (i - 64);
-  *dst = accumulate ? *dst + s : s;
 }
 
 // =====================================================================================================================
@@ -1275,18 +1290,6 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void conv2_bwd_weight_final(const float* __restrict__ sums,
-                                                              float* __restrict__ dw, float* __restrict__ db) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 4608 + 32) return;
-  const float s = sums[i];
-  if (i < 4608) {
-    const int ci = i & 15, tap = (i >> 4) % 9, o = i / 144;
-    dw[(o * 16 + ci) * 9 + tap] = s;
-  } else {
-    db[i - 4608] = s;
-  }
-}
 
 inline int conv1_slabs(int64_t total) {
   int64_t b = (total + 256 * 8 - 1) / (256 * 8);
@@ -1385,9 +1388,7 @@ extern "C" int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_bwd_weight_kernel<T>, dim3(nslabs), dim3(256), 0, s, (const T*)dp1, code1,
                                        x, B, H, W, H1, W1, (float*)workspace));
   float* scratch = (float*)workspace + (size_t)nslabs * 80;
-  float* sums = scratch + 64 * 80;
-  launch_slab_sum((const float*)workspace, nslabs, 80, scratch, sums, s);
-  hipLaunchKernelGGL(conv1_bwd_weight_final, dim3(1), dim3(128), 0, s, (const float*)sums, dw, db, accumulate);
+  launch_slab_sum<1>((const float*)workspace, nslabs, 80, scratch, dw, db, accumulate, s);
   GDM_LAUNCH_OK("gdm_simnn_conv1_bwd_weight");
   return GDM_OK;
 }
@@ -1510,9 +1511,7 @@ extern "C" int gdm_simnn_conv2_bwd_fused_finish(int B, int H1, int W1, float* dw
   const int nblocks = bd_plan(B, H1, W1, true).blocks;
   float* slabs = (float*)workspace;
   float* scratch = slabs + (size_t)nblocks * 80;
-  float* sums = scratch + 64 * 80;
-  launch_slab_sum(slabs, nblocks, 80, scratch, sums, s);
-  hipLaunchKernelGGL(conv1_bwd_weight_final, dim3(1), dim3(128), 0, s, (const float*)sums, dw1, db1, 0);
+  launch_slab_sum<1>(slabs, nblocks, 80, scratch, dw1, db1, 0, s);
   GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_fused_finish");
   return GDM_OK;
 }
@@ -1552,10 +1551,7 @@ extern "C" int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2,
                        (float*)workspace);
   }
   float* scratch = (float*)workspace + (size_t)nblocks * (4608 + 32);
-  float* sums = scratch + (size_t)64 * (4608 + 32);
-  launch_slab_sum((const float*)workspace, nblocks, 4608 + 32, scratch, sums, s);
-  hipLaunchKernelGGL(conv2_bwd_weight_final, dim3((4608 + 32 + 255) / 256), dim3(256), 0, s, (const float*)sums, dw,
-                     db);
+  launch_slab_sum<2>((const float*)workspace, nblocks, 4608 + 32, scratch, dw, db, 0, s);
   GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_weight");
   return GDM_OK;
 }
