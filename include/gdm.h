@@ -97,9 +97,10 @@ int gdm_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n
 
 /* ---- model 1 discriminator, convolution trunk (SIMNN.py:123-125,136-139) ---------------------------------------
  * conv1: Conv2d(1,16,k2,s1,p1)+ReLU+MaxPool2 fused (aten::convolution/relu/max_pool2d_with_indices):
- *   x (B,H,W) fp32 -> p1 (B,H1,W1,16) channels-last `dtype`, code1 (B,H1,W1) uint64: bits [2c+1:2c] = argmax
- *   position (dy*2+dx, first maximum in scan order) of channel c, bit 32+c = channel c passes gradient
- *   (pooled value > 0); H1=(H+1)/2, W1=(W+1)/2.
+ *   x (B,H,W) fp32 -> p1 (B,H1,W1,16) channels-last `dtype`, code1 (B,H1,W1) uint64 = four 16-bit fields, field g
+ *   (bits 16g..16g+15) for channels 4g..4g+3: bits [2r+1:2r] = argmax position (dy*2+dx, first maximum in scan
+ *   order) of channel 4g+r, bit 8+r = that channel passes gradient (pooled value > 0); H1=(H+1)/2, W1=(W+1)/2.
+ *   code1 is only ever read back by gdm_simnn_conv1_bwd_weight / gdm_simnn_conv2_bwd_fused.
  * conv2: Conv2d(16,32,k3,s1,p1)+ReLU+MaxPool2 fused, implicit GEMM on MFMA:
  *   p1 -> p2 (B,H2,W2,32) channels-last, code2 (B,H2,W2,32) uint8 (0..3 = argmax position in scan order,
  *   4 = ReLU-dead), H2=H1/2, W2=W1/2.  The reference flattens channel-major (x.view(-1, 32*32*54), SIMNN.py:139);
