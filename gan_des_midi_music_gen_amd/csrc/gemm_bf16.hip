@@ -36,6 +36,14 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
                                            __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+// Lanes of one wave exchange data through LDS without a workgroup barrier (the wave-private epilogue scratch): the
+// compiler reasons per thread and would otherwise move the scratch stores under the (per-lane) condition of the loads.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ bf16x4 lds_tr16(const __bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
 }
@@ -265,8 +273,10 @@ __global__ __launch_bounds__(NT) void gemm_bf16_fast(GemmArgs g) {
       const bool has_bias = g.bias_n || g.bias_m;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        wave_lds_sync();                     // the previous pass's scratch reads are done
 #pragma unroll
         for (int j = 0; j < 4; ++j) *(f32x4*)&scr[lr * 64 + 4 * ((4 * j + lg) ^ lr)] = acc[i][j];
+        wave_lds_sync();
         if (is_bf16) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) {

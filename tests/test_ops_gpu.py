@@ -102,6 +102,23 @@ def test_gemm_bf16_vector_path_all_layouts(ta, tb, a_kmaj, b_kmaj):
         _close(out, ref[:, :262] + bias[:262], 2e-3, "fast gemm ragged N")
 
 
+@pytest.mark.parametrize("ta", ["f32", "bf16"])
+@pytest.mark.parametrize("out_dt", [F32, BF16])
+@pytest.mark.parametrize("m,n", [(200, 1096), (512, 4096), (64, 1024)])
+def test_gemm_k128_row_major_b(ta, out_dt, m, n):
+    """fc1's data-gradient shape: K == 128, K-major A, row-major bf16 B, no epilogue; ragged M and N tails (N % 16 == 8
+    exercises the row-contiguous epilogue with half-valid lanes)."""
+    g = torch.Generator().manual_seed(m + n)
+    a = torch.randn(m, 128, generator=g)
+    b = torch.randn(128, n, generator=g) / 128 ** 0.5
+    ad = a.to(DEV) if ta == "f32" else a.to(torch.bfloat16).to(DEV)
+    bd = b.to(torch.bfloat16).to(DEV)
+    out = ops.gemm(ad, bd, compute=BF16, out_dtype=out_dt)
+    _close(out, _rb(a) @ _rb(b), 2e-3 if out_dt == F32 else 1e-2, "k128 gemm")
+    out2 = ops.gemm(ad, bd, compute=BF16, out_dtype=out_dt)
+    assert torch.equal(out, out2)
+
+
 def test_bce_with_logits():
     g = torch.Generator().manual_seed(3)
     for n, target in ((16, 0.9), (256, 0.1), (2048, 1.0), (7, 0.0)):
