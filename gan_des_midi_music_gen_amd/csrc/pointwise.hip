@@ -499,7 +499,7 @@ extern "C" int gdm_cast(const void* src, int src_dtype, void* dst, int dst_dtype
 // rows [0, n0) carry label y0, rows [n0, n) label y1 (n0 == n: a single label).  All reductions in fixed order.
 // =====================================================================================================================
 namespace {
-constexpr int HEAD_ROWS = 32;   // batch rows per workgroup
+constexpr int HEAD_ROWS = 8;    // batch rows per workgroup (a launch is latency-bound: many short workgroups)
 // partial layout per workgroup: [0,128) dw2, [128,256) db1, [256] db2, [257] loss
 __global__ __launch_bounds__(256) void simnn_head_kernel(const float* __restrict__ h1, const float* __restrict__ w2,
                                                          const float* __restrict__ b2, int n, int n0, float y0,
@@ -579,8 +579,16 @@ __global__ __launch_bounds__(320) void simnn_head_final(const float* __restrict_
                                                         float* __restrict__ db1) {
   const int t = threadIdx.x;
   if (t >= 258) return;
-  float s = 0.f;
-  for (int g = 0; g < groups; ++g) s += partials[(int64_t)g * 258 + t];
+  // eight independent partial sums (fixed assignment and order): the loads of a trip issue back to back instead of
+  // one dependent load per group
+  float p8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int g = 0;
+  for (; g + 8 <= groups; g += 8) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) p8[q] += partials[(int64_t)(g + q) * 258 + t];
+  }
+  for (int q = 0; g < groups; ++g, ++q) p8[q] += partials[(int64_t)g * 258 + t];
+  const float s = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
   if (t == 257) loss[0] = (accumulate_loss ? loss[0] : 0.f) + s;
   else if (dw2 != nullptr) {
     if (t < 128) dw2[t] = s;
