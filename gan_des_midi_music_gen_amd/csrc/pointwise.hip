@@ -587,7 +587,7 @@ __global__ __launch_bounds__(320) void simnn_head_final(const float* __restrict_
 #pragma unroll
     for (int q = 0; q < 8; ++q) p8[q] += partials[(int64_t)(g + q) * 258 + t];
   }
-  for (int q = 0; g < groups; ++g, ++q) p8[q] += partials[(int64_t)g * 258 + t];
+  for (; g < groups; ++g) p8[0] += partials[(int64_t)g * 258 + t];      // (no run-time register index)
   const float s = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
   if (t == 257) loss[0] = (accumulate_loss ? loss[0] : 0.f) + s;
   else if (dw2 != nullptr) {

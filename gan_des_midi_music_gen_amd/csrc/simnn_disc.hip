@@ -288,16 +288,17 @@ __global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict_
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   const int k0 = blockIdx.y * per_group, k1 = min(nslabs, k0 + per_group);
-  float s0 = 0.f, s1 = 0.f;
+  // wave wv adds slabs k0 + wv + 16 j; eight independent partial sums so that eight row loads are in flight at once
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (i < width) {
     int k = k0 + wv;
-    for (; k + 16 < k1; k += 32) {
-      s0 += slabs[(int64_t)k * width + i];
-      s1 += slabs[(int64_t)(k + 16) * width + i];
+    for (; k + 16 * 7 < k1; k += 16 * 8) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s8[q] += slabs[(int64_t)(k + 16 * q) * width + i];
     }
-    if (k < k1) s0 += slabs[(int64_t)k * width + i];
+    for (; k < k1; k += 16) s8[0] += slabs[(int64_t)k * width + i];      // (no run-time register index)
   }
-  part[wv][lane] = s0 + s1;
+  part[wv][lane] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   __syncthreads();
   if (wv == 0 && i < width) {
     float t = part[0][lane];
