@@ -12,6 +12,7 @@
 //
 // T = float : exact-fp32 mode, v_mfma_f32_16x16x4_f32, LDS pixel records padded to avoid bank conflicts
 // T = __bf16: bf16 storage + v_mfma_f32_16x16x32_bf16, fp32 accumulation
+#include <cstdlib>
 #include "gdm_common.h"
 
 namespace {
@@ -1111,7 +1112,9 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
   int s = blockIdx.x, b, c0, rq_first, rq_end;            // host guarantees gridDim.x <= n_items
   place(s, b, c0, rq_first, rq_end);
   int rq = rq_first - 1;                                   // pseudo step: brings in p1 rows 4 rq_first - 1 and 4 rq_first
+  STAMP_DECL;
   issue(b, c0, rq, false);
+  STAMP(4);
 
   // per-lane fragment addresses that never change: swizzled p1 band columns for (segment, kw, lo/hi)
   int pcol_off[2][3][2];
@@ -1127,6 +1130,10 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
   }
 
   while (s < n_items) {
+#ifdef GDM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(5);
+#endif
     // ---- registers -> LDS: dc2 rows of this step, p1 ring rows 4rq+1 .. 4rq+4
     if (rq >= rq_first) {
       const uint64_t cd = rg.cd;
@@ -1190,7 +1197,9 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
         for (int e = 0; e < 4; ++e) { dst[e] = rg.p[k][e]; dst[4 + e] = rg.p[BW<T>::P1IT + k][e]; }
       }
     }
+    STAMP(6);
     __syncthreads();
+    STAMP(0);
     // ---- next step's loads (always issued: the very last step re-reads its own rows)
     int sn = s, bn = b, c0n = c0, rqn = rq + 1, rq_first_n = rq_first, rq_end_n = rq_end;
     if (rqn == rq_end) {
@@ -1203,6 +1212,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
       }
     }
     issue(bn, c0n, rqn, rqn >= rq_first_n);
+    STAMP(1);
 
     if (rq >= rq_first) {
       // wave wv contracts row wv of the step (64 pixels = 2 bf16 k-steps / 16 fp32 k-steps)
@@ -1255,9 +1265,12 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
         }
       }
     }
+    STAMP(2);
     __syncthreads();   // this step's readers are done: the LDS images may be rebuilt
+    STAMP(3);
     s = sn; b = bn; c0 = c0n; rq = rqn; rq_first = rq_first_n; rq_end = rq_end_n;
   }
+  STAMP_FLUSH;
   // ---- cross-wave reduction in fixed order (wave 0 stores, waves 1..3 add in turn: each element is touched by the
   //      same lane position in every wave) and slab write.  slab layout: [o 32][tap 9][ci 16] then 32 bias sums.
   __syncthreads();
@@ -1311,23 +1324,26 @@ inline BdPlan bd_plan(int B, int H1, int W1, bool fuse) {
   p.seg_len = (nrq + nseg - 1) / nseg;
   p.nseg = (nrq + p.seg_len - 1) / p.seg_len;
   p.n_items = (int)(strips * p.nseg);
-  const int cap = fuse ? 512 : 768;
+  const int cap = fuse ? 512 : 768;      // (measured at 2B = 512: 384 -> 132 us, 512 -> 118, 640 -> 121, 768 -> 121)
   p.blocks = p.n_items < cap ? p.n_items : cap;
   return p;
 }
-// conv2 backward-weight: same items, up to 4 resident workgroups per CU, small batches cut finer
+// conv2 backward-weight: same items, 3 resident workgroups per CU, small batches cut finer
 inline BdPlan bw_plan(int B, int H1, int W1) {
   BdPlan p;
   const int nrq = (H1 + ROWS - 1) / ROWS;
   p.n_ctiles = (W1 + COLS - 1) / COLS;
   const int64_t strips = (int64_t)B * p.n_ctiles;
+  // measured at 2B = 512 (1024 strips): 768 workgroups (3 per CU) 73 us, 1024 (4 per CU) 84 us, 512 78 us; finer items
+  // (more segments per strip) only add pseudo steps
+  constexpr int cap = 768;
   int nseg = (int)((1024 + strips - 1) / strips);
   const int max_seg = nrq / 2 > 1 ? nrq / 2 : 1;
   nseg = nseg < 1 ? 1 : (nseg > max_seg ? max_seg : nseg);
   p.seg_len = (nrq + nseg - 1) / nseg;
   p.nseg = (nrq + p.seg_len - 1) / p.seg_len;
   p.n_items = (int)(strips * p.nseg);
-  p.blocks = p.n_items < 1024 ? p.n_items : 1024;
+  p.blocks = p.n_items < cap ? p.n_items : cap;
   return p;
 }
 

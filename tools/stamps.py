@@ -34,7 +34,7 @@ def main():
     dp2 = torch.randn_like(p2.float()).to(torch.bfloat16)
     names = {"fwd": ["store->barrier", "issue", "mfma", "epilogue", "end barrier", "prologue", "wait+ds_write", "-"],
              "bwd": ["expand->barrier", "issue", "mfma", "dp1 store", "gather epilogue", "end barrier", "prologue", "wait+expand"],
-             "bww": ["expand+store->barrier", "issue", "mfma", "end barrier", "prologue", "-", "-", "-"]}[which]
+             "bww": ["barrier", "issue", "mfma", "end barrier", "prologue", "wait for loads", "expand + p1 store", "-"]}[which]
     fn = {"fwd": lambda: ops.simnn_conv2_fwd(p1, pack, b2),
           "bwd": lambda: ops.simnn_conv2_bwd_fused(dp2, code2, pack, code1, x),
           "bww": lambda: ops.simnn_conv2_bwd_weight(dp2, code2, p1)}[which]
