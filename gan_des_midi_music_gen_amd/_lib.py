@@ -21,6 +21,9 @@ SIGNATURES = {
     "gdm_bce_with_logits": (_I, [_P, _F, _I, _F, _P, _P, _I, _I, _P]),
     "gdm_adam_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P]),
     "gdm_adam_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P]),
+    "gdm_stft_frames": (_I, [_P, _I, _L, _L, _I, _I, _I, _P, _P]),
+    "gdm_power_spectrum": (_I, [_P, _L, _I, _I, _P, _P]),
+    "gdm_power_to_db": (_I, [_P, _I, _I, _I, _F, _F, _P, _P]),
     "gdm_bn_workspace_bytes": (_Z, [_I, _I]),
     "gdm_bn_act_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P, _I, _P, _P, _I, _P, _Z, _P]),
     "gdm_bn_act_bwd": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),

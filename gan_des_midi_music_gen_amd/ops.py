@@ -485,3 +485,36 @@ def permute_pc(src, b, p, c, out_dtype=None, out=None):
     assert out.is_contiguous() and out.numel() == b * p * c
     _call("gdm_permute_pc", _p(src), gdm_dtype(src), b, p, c, _p(out), gdm_dtype(out), _stream())
     return out
+
+
+# ---- mel-spectrogram featuriser kernels (GAN_DES/util.py:37-61) -------------------------------------------------------
+def stft_frames(x, hop, n_fft):
+    """x (B, L) fp32 -> (B * frames, n_fft) centred, reflect-padded frames; frames = 1 + L // hop."""
+    _need_gpu(x)
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    b, l = x.shape
+    frames = 1 + l // hop
+    out = torch.empty((b * frames, n_fft), dtype=torch.float32, device=x.device)
+    _call("gdm_stft_frames", _p(x), b, l, x.stride(0), int(hop), int(n_fft), frames, _p(out), _stream())
+    return out, frames
+
+
+def power_spectrum(c, nfreq, ldp=None):
+    """c (rows, 2 * nfreq) = [re | im] -> (rows, ldp) power, zero padded beyond nfreq."""
+    _need_gpu(c)
+    assert c.dim() == 2 and c.shape[1] == 2 * nfreq and c.dtype == torch.float32 and c.is_contiguous()
+    ldp = nfreq if ldp is None else ldp
+    p = torch.empty((c.shape[0], ldp), dtype=torch.float32, device=c.device)
+    _call("gdm_power_spectrum", _p(c), c.shape[0], int(nfreq), int(ldp), _p(p), _stream())
+    return p
+
+
+def power_to_db(mel, b, frames, top_db=80.0, amin=1e-10):
+    """mel (b * frames, n_mels) power -> (b, n_mels, frames) dB with the per-window top_db floor."""
+    _need_gpu(mel)
+    assert mel.dim() == 2 and mel.shape[0] == b * frames and mel.dtype == torch.float32 and mel.is_contiguous()
+    n_mels = mel.shape[1]
+    out = torch.empty((b, n_mels, frames), dtype=torch.float32, device=mel.device)
+    _call("gdm_power_to_db", _p(mel), int(b), int(frames), int(n_mels), float(-1.0 if top_db is None else top_db),
+          float(amin), _p(out), _stream())
+    return out

@@ -195,6 +195,20 @@ int gdm_col2im(const void* cols, int cols_dtype, int B, int H, int W, int C, int
  * flatten order: activations, and fc1's weight / weight gradient viewed as (128, 32, H2*W2) <-> (128, H2*W2, 32)). */
 int gdm_permute_pc(const void* src, int src_dtype, int B, int P, int C, void* dst, int dst_dtype, void* stream);
 
+/* ---- mel-spectrogram featuriser (GAN_DES/util.py:37-61: torchaudio MelSpectrogram + AmplitudeToDB) --------------
+ * The producer of model 1's discriminator input.  DFT and mel filter bank are gdm_gemm calls in exact fp32 (window
+ * folded into the [cos | sin] matrix); these three functions are the kernels around them.
+ * gdm_stft_frames: x (B windows of L samples, x_stride apart) -> out (B*frames, n_fft) centred frames, reflect padding
+ *   (torch.stft center=True, pad_mode="reflect"; frames = 1 + L / hop).
+ * gdm_power_spectrum: c (rows, 2*nfreq) = [re | im] -> p (rows, ldp) = re^2 + im^2 (Spectrogram power=2); columns
+ *   nfreq..ldp-1 are zero padding for the following GEMM.
+ * gdm_power_to_db: mel (B, frames, n_mels) -> out (B, n_mels, frames) = max(10 log10(max(mel, amin)),
+ *   window max - top_db)  (AmplitudeToDB(stype="power", top_db); top_db < 0 = no floor).                             */
+int gdm_stft_frames(const float* x, int B, int64_t L, int64_t x_stride, int hop, int n_fft, int frames, float* out,
+                    void* stream);
+int gdm_power_spectrum(const float* c, int64_t rows, int nfreq, int ldp, float* p, void* stream);
+int gdm_power_to_db(const float* mel, int B, int frames, int n_mels, float top_db, float amin, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
