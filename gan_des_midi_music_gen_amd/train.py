@@ -160,11 +160,11 @@ class SimnnTrainer(_TrainerBase):
 
     def _streams(self, dev):
         if self._side is None:
-            self._side = [torch.cuda.Stream(dev) for _ in range(3)]
+            self._side = [torch.cuda.Stream(dev) for _ in range(2)]
         return self._side
 
     def _d_backward(self, saved, dh, pack, wf1p, outs, x_pair, keep):
-        """Discriminator backward below the head: three independent branches after dh1 / dp2 are known."""
+        """Discriminator backward below the head: fc1's weight gradient runs beside the data-gradient chain."""
         dt = self.dt
         x, p1, code1, flat, code2 = saved[:5]
         b = p1.shape[0]
@@ -186,17 +186,14 @@ class SimnnTrainer(_TrainerBase):
         h1s, w1s = p1.shape[1], p1.shape[2]
         dp2 = dflat.view(b, h1s // 2, w1s // 2, 32)
         keep.append(dflat)
-        # branch B: conv2 weight gradient
-        if side:
-            side[2].wait_stream(main)
-        with torch.cuda.stream(side[2] if side else main):
-            ops.simnn_conv2_bwd_weight(dp2, code2, p1, out=(outs[2], outs[3]))
-        # main: conv2 data gradient with conv1's weight gradient fused in
+        # conv2 weight gradient, then conv2 data gradient with conv1's weight gradient fused in: both on the main
+        # stream -- they are issue-bound persistent kernels that fill the chip, side by side they only take turns
+        # (tools/overlap_probe.py), and one after the other each runs at its own speed
+        ops.simnn_conv2_bwd_weight(dp2, code2, p1, out=(outs[2], outs[3]))
         x0, x1 = x_pair if x_pair is not None else (x, None)
         ops.simnn_conv2_bwd_fused(dp2, code2, pack, code1, x0, x1, out=(outs[0], outs[1]))
         if side:
             main.wait_stream(side[1])
-            main.wait_stream(side[2])
 
     @torch.no_grad()
     def step(self, real, noise, fake):
