@@ -115,28 +115,42 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
       }
 }
 
-// Sums the split-K slabs in a fixed order (4 interleaved partial sums over z so that the loads pipeline), then applies
-// the epilogue.  VEC: 4 consecutive n per lane (N % 4 == 0, row-major C).
+// Sums the split-K slabs in a fixed order, then applies the epilogue.  The kernel is a chain of memory latencies over
+// few outputs, so it is spread wide: VEC (N % 4 == 0, row-major C): a workgroup owns 64 output vectors (4 consecutive n
+// each); its four waves each sum one contiguous quarter of the slabs (4 interleaved partial sums so that the loads
+// pipeline) and wave 0 adds the four quarter sums in order.
 template <bool VEC>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce(GemmArgs g) {
   const int64_t total = (int64_t)g.M * g.N;
-  const int64_t idx = ((int64_t)blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1);
-  if (idx >= total) return;
   if constexpr (VEC) {
+    __shared__ f32x4 part[4][64];
+    const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
+    const int64_t idx = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    const bool live = idx < total;
+    const int q4 = (g.split_k + 3) / 4;
+    const int z0 = zg * q4, z1 = min(g.split_k, z0 + q4);
     f32x4 s[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) s[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int z = 0;
-    for (; z + 3 < g.split_k; z += 4) {
+    if (live) {
+      int z = z0;
+      for (; z + 3 < z1; z += 4) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) s[q] += *(const f32x4*)(g.ws + (int64_t)(z + q) * total + idx);
+        for (int q = 0; q < 4; ++q) s[q] += *(const f32x4*)(g.ws + (int64_t)(z + q) * total + idx);
+      }
+      for (; z < z1; ++z) s[0] += *(const f32x4*)(g.ws + (int64_t)z * total + idx);
     }
-    for (; z < g.split_k; ++z) s[0] += *(const f32x4*)(g.ws + (int64_t)z * total + idx);
-    const f32x4 v = (s[0] + s[1]) + (s[2] + s[3]);
-    const int m = (int)(idx / g.N), n = (int)(idx % g.N);
+    part[zg][lane] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (zg == 0 && live) {
+      const f32x4 v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+      const int m = (int)(idx / g.N), n = (int)(idx % g.N);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) gemm_epilogue_store(g, m, n + r, v[r]);
+      for (int r = 0; r < 4; ++r) gemm_epilogue_store(g, m, n + r, v[r]);
+    }
   } else {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     int z = 0;
     for (; z + 3 < g.split_k; z += 4) {
@@ -152,7 +166,7 @@ int launch_splitk_reduce(const GemmArgs& g, hipStream_t s) {
   if (g.split_k > 1) {
     const int64_t total = (int64_t)g.M * g.N;
     if (g.N % 4 == 0) {
-      hipLaunchKernelGGL(gemm_splitk_reduce<true>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, g);
+      hipLaunchKernelGGL(gemm_splitk_reduce<true>, dim3((unsigned)((total / 4 + 63) / 64)), dim3(256), 0, s, g);
     } else {
       hipLaunchKernelGGL(gemm_splitk_reduce<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g);
     }
