@@ -76,6 +76,10 @@ def load():
                 raise GdmError(
                     f"{LIB_PATH} is missing: build it with `python -m gan_des_midi_music_gen_amd.build` "
                     "(hipcc --offload-arch=gfx950). There is no CPU or eager-PyTorch fallback for this path.")
+            # PyTorch-ROCm ships its own libamdhip64: it must be in the process BEFORE this library's dependency on
+            # libamdhip64.so is resolved, or the process ends up with two HIP runtimes and our kernels are registered
+            # with the one that owns no device ("no ROCm-capable device is detected" on the first launch).
+            import torch  # noqa: F401
             lib = ctypes.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)  # AttributeError if the symbol is not exported
