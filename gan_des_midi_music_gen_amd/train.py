@@ -320,16 +320,21 @@ class MmganTrainer(_TrainerBase):
         return [(blk[0].weight.detach(), blk[0].bias.detach(), blk[1].weight.detach(), blk[1].bias.detach(),
                  blk[1].running_mean, blk[1].running_var, blk[1].num_batches_tracked) for blk in gen.gen]
 
-    def _generators_forward(self, noise1, noise2, beats, g1_input):
+    def _generators_forward(self, noise1, noise2, beats, g1_input, streams=None):
+        """Both generators (network_tests.py:186-187).  They are independent chains of four latency-bound
+        Linear+BN+Sigmoid launches: with ``streams`` = (s1, s2) each chain runs on its own stream."""
         mm, dt = self.mm, self.dt
         if g1_input is None:   # network_tests.py:83-84: drawn on the CPU generator, then moved
             g1_input = torch.randn(len(noise1), mm.generator1.input_tensor_dim).to(noise1.device)
-        x1 = torch.cat((noise1, g1_input), dim=1)
-        x2 = torch.cat((noise2, beats), dim=1)
-        o1, _ = Fn.mlp_bn_sigmoid_forward(x1, self._layers(mm.generator1), mm.generator1.training, dt,
-                                          need_backward=False)
-        o2, _ = Fn.mlp_bn_sigmoid_forward(x2, self._layers(mm.generator2), mm.generator2.training, dt,
-                                          need_backward=False)
+        s1, s2 = streams if streams is not None else (None, None)
+        with torch.cuda.stream(s1 if s1 is not None else torch.cuda.current_stream()):
+            x1 = torch.cat((noise1, g1_input), dim=1)
+            o1, _ = Fn.mlp_bn_sigmoid_forward(x1, self._layers(mm.generator1), mm.generator1.training, dt,
+                                              need_backward=False)
+        with torch.cuda.stream(s2 if s2 is not None else torch.cuda.current_stream()):
+            x2 = torch.cat((noise2, beats), dim=1)
+            o2, _ = Fn.mlp_bn_sigmoid_forward(x2, self._layers(mm.generator2), mm.generator2.training, dt,
+                                              need_backward=False)
         a = mm.generator1.adj_size
         return o1.view(len(noise1), -1, a[0], a[1]), o2
 
@@ -347,18 +352,23 @@ class MmganTrainer(_TrainerBase):
         t = piano_roll.shape[2]
         dev = piano_roll.device
         fused = self._fused_ok(t)
-        # the generators only feed the (external) bridge: they run on a side stream beside the discriminator kernels
+        # the generators only feed the (external) bridge: each runs on a side stream of its own beside the
+        # discriminator kernels (a generator's second forward follows its first one: BN running statistics)
         main = torch.cuda.current_stream()
         if self._gen_stream is None:
-            self._gen_stream = torch.cuda.Stream(dev)
-        side = self._gen_stream
+            self._gen_stream = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        sides = self._gen_stream
+        # (a branch forked at the very root of a captured graph was observed to run before, not beside, the main
+        # branch: fork after a first small launch on the main stream)
+        self.d.extra[2:].zero_()
         # --- D step (network_tests.py:293-308)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            g1, g2 = self._generators_forward(noise1, noise2, beats, g1_in_a)
+        for sd in sides:
+            sd.wait_stream(main)
+        g1, g2 = self._generators_forward(noise1, noise2, beats, g1_in_a, sides)
         self.last_g1, self.last_g2 = g1, g2
         if callable(fake_a):
-            main.wait_stream(side)
+            for sd in sides:
+                main.wait_stream(sd)
             fake_a = fake_a(g1, g2)
         if fused:
             if self._pack is None:
@@ -384,10 +394,10 @@ class MmganTrainer(_TrainerBase):
         if fused:
             ops.dcnn_pack(w1, b1, w2, b2, wf, bf, t, out=self._pack)     # weights changed: refresh in place
         # --- "G" step (311-315): both generators run again (2nd BN statistics update), D forward on the new fake
-        with torch.cuda.stream(side):
-            g1b, g2b = self._generators_forward(noise1, noise2, beats, g1_in_b)
+        g1b, g2b = self._generators_forward(noise1, noise2, beats, g1_in_b, sides)
         if callable(fake_b):
-            main.wait_stream(side)
+            for sd in sides:
+                main.wait_stream(sd)
             fake_b = fake_b(g1b, g2b)
         if fused:
             if self.elide:
@@ -404,7 +414,8 @@ class MmganTrainer(_TrainerBase):
             else:
                 _, dlg = ops.bce_with_logits(logits_g.view(-1), 1.0, loss_out=self.loss_g)
                 Fn.dcnn_backward(saved_g, dlg, w2, wf, dt)     # dead values (only D's .grad in the reference)
-        main.wait_stream(side)
+        for sd in sides:
+            main.wait_stream(sd)
         self.iterations += 1
         return self.loss_d, self.loss_g
 
