@@ -375,44 +375,56 @@ __global__ __launch_bounds__(NTHREADS) void dcnn_fused_kernel(const float* __res
 }
 
 // ---- slab reduction + unpack into the torch gradient tensors -----------------------------------------------------------
+// Fixed-order sum over slabs (wave w adds slabs w, w+16, ...; four independent partial sums so that the row loads
+// overlap).  FINISH: the last level writes straight into the loss slot / the six gradient tensors (slab element i ->
+// its torch position; dwfc is stored pixel-major in the slab and channel-major in torch).
+struct DcnnSinks {
+  float* loss; int accumulate_loss; int want_grad;
+  float *dw1, *db1, *dw2, *db2, *dwfc, *dbfc;
+  int T;
+};
+
+template <bool FINISH>
 __global__ __launch_bounds__(1024) void dcnn_slab_sum(const float* __restrict__ slabs, int nslabs, int per_group,
-                                                      int width, float* __restrict__ out) {
+                                                      int width, float* __restrict__ out, DcnnSinks k) {
   __shared__ float part[16][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   const int k0 = blockIdx.y * per_group, k1 = min(nslabs, k0 + per_group);
-  float s = 0.f;
-  if (i < width)
-    for (int k = k0 + wv; k < k1; k += 16) s += slabs[(int64_t)k * width + i];
-  part[wv][lane] = s;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < width) {
+    int q = k0 + wv;
+    for (; q + 48 < k1; q += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s4[u] += slabs[(int64_t)(q + 16 * u) * width + i];
+    }
+    for (; q < k1; q += 16) s4[0] += slabs[(int64_t)q * width + i];
+  }
+  part[wv][lane] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
   __syncthreads();
   if (wv == 0 && i < width) {
     float tsum = part[0][lane];
 #pragma unroll
     for (int w = 1; w < 16; ++w) tsum += part[w][lane];
-    out[(int64_t)blockIdx.y * width + i] = tsum;
+    if constexpr (!FINISH) {
+      out[(int64_t)blockIdx.y * width + i] = tsum;
+    } else {
+      if (i == S_LOSS) { k.loss[0] = (k.accumulate_loss ? k.loss[0] : 0.f) + tsum; return; }
+      if (!k.want_grad) return;
+      if (i == S_DBFC) k.dbfc[0] = tsum;
+      else if (i < S_DB2) k.db1[i - S_DB1] = tsum;
+      else if (i < S_DW1) k.db2[i - S_DB2] = tsum;
+      else if (i < S_DW2) k.dw1[i - S_DW1] = tsum;
+      else if (i < S_DWFC) k.dw2[i - S_DW2] = tsum;
+      else {                                       // slab: k' = pix*32 + c   ->   torch: c*P + pix
+        const Dims d(k.T);
+        const int kp = i - S_DWFC, P = OH2 * d.OW2;
+        if (kp < d.KFC) k.dwfc[(kp & 31) * P + (kp >> 5)] = tsum;
+      }
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void dcnn_finish_kernel(const float* __restrict__ sums, int T, int want_grad,
-                                                          float* __restrict__ loss, int accumulate_loss,
-                                                          float* __restrict__ dw1, float* __restrict__ db1,
-                                                          float* __restrict__ dw2, float* __restrict__ db2,
-                                                          float* __restrict__ dwfc, float* __restrict__ dbfc) {
-  const Dims d(T);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i == 0) loss[0] = (accumulate_loss ? loss[0] : 0.f) + sums[S_LOSS];
-  if (!want_grad) return;
-  if (i == 0) dbfc[0] = sums[S_DBFC];
-  if (i < 16) db1[i] = sums[S_DB1 + i];
-  if (i < 32) db2[i] = sums[S_DB2 + i];
-  if (i < 512) dw1[i] = sums[S_DW1 + i];
-  if (i < 8192) dw2[i] = sums[S_DW2 + i];
-  if (i < d.KFC) {                                  // i = c*P + pix (torch order)  <-  k' = pix*32 + c
-    const int P = OH2 * d.OW2, c = i / P, pix = i % P;
-    dwfc[i] = sums[S_DWFC + pix * 32 + c];
-  }
-}
 
 inline size_t lds_bytes(const Dims& d) {
   return (size_t)(d.xs_elems() + d.h1_elems() + d.d2_elems() + W_ELEMS) * 2 + 64 * sizeof(float);
@@ -477,19 +489,19 @@ extern "C" int gdm_dcnn_fused(const float* xa, int bsplit, const float* p0, cons
   hipLaunchKernelGGL(dcnn_fused_kernel, dim3(nb), dim3(NTHREADS), lds_bytes(d), s, xa, bsplit, p0, p1, B, T, ya, yb,
                      (const __bf16*)pack, logits, slabs, width, want_grad);
   float* scratch = slabs + (size_t)nb * width;      // up to 64 group partials
-  float* sums = scratch + (size_t)64 * width;
   const int groups = nb <= 32 ? 1 : (nb + 31) / 32;
   const int per = (nb + groups - 1) / groups;
   const unsigned gx = (unsigned)((width + 63) / 64);
+  const DcnnSinks sinks{loss, accumulate_loss, want_grad, dw1, db1, dw2, db2, dwfc, dbfc, T};
   if (groups == 1) {
-    hipLaunchKernelGGL(dcnn_slab_sum, dim3(gx, 1), dim3(1024), 0, s, (const float*)slabs, nb, per, width, sums);
+    hipLaunchKernelGGL(dcnn_slab_sum<true>, dim3(gx, 1), dim3(1024), 0, s, (const float*)slabs, nb, per, width,
+                       (float*)nullptr, sinks);
   } else {
-    hipLaunchKernelGGL(dcnn_slab_sum, dim3(gx, groups), dim3(1024), 0, s, (const float*)slabs, nb, per, width, scratch);
-    hipLaunchKernelGGL(dcnn_slab_sum, dim3(gx, 1), dim3(1024), 0, s, (const float*)scratch, groups, groups, width, sums);
+    hipLaunchKernelGGL(dcnn_slab_sum<false>, dim3(gx, groups), dim3(1024), 0, s, (const float*)slabs, nb, per, width,
+                       scratch, sinks);
+    hipLaunchKernelGGL(dcnn_slab_sum<true>, dim3(gx, 1), dim3(1024), 0, s, (const float*)scratch, groups, groups, width,
+                       (float*)nullptr, sinks);
   }
-  const int nfin = want_grad ? (d.KFC > 8192 ? d.KFC : 8192) : 1;
-  hipLaunchKernelGGL(dcnn_finish_kernel, dim3((nfin + 255) / 256), dim3(256), 0, s, (const float*)sums, T, want_grad,
-                     loss, accumulate_loss, dw1, db1, dw2, db2, dwfc, dbfc);
   GDM_LAUNCH_OK("gdm_dcnn_fused");
   return GDM_OK;
 }
