@@ -13,6 +13,7 @@
 //   conv2 dW    M=32 oc,  N=16 ci per tap,      K=pixels                  both operands via ds_read_b64_tr_b16
 //   conv2 dX    M=16 ci,  N=16 same-parity pixels of a row, K=128 (2x2 taps of the parity class, 32 oc)
 //   conv1 dW    M=16 oc,  N=2x16 (kh,kw,ci),    K=pixels                  both operands via ds_read_b64_tr_b16
+#include <cstdlib>
 #include "gdm_common.h"
 
 namespace {
@@ -429,7 +430,20 @@ __global__ __launch_bounds__(1024) void dcnn_slab_sum(const float* __restrict__ 
 inline size_t lds_bytes(const Dims& d) {
   return (size_t)(d.xs_elems() + d.h1_elems() + d.d2_elems() + W_ELEMS) * 2 + 64 * sizeof(float);
 }
-inline int n_blocks(int B) { return B < 256 ? B : 256; }
+// One persistent workgroup per CU (151 KB of LDS each) -- on 7/8 of the CUs: a workgroup of this kernel owns its CU's
+// LDS, so nothing else can run beside it there; the training step runs the generators' latency-bound launches on
+// side streams, and they need somewhere to land (measured, model-2 step at B = 256: 256 workgroups 0.319 ms,
+// 224 -> 0.255 ms, 192 -> 0.252 ms, 160 -> 0.275 ms; alone the kernel is ~12 % slower on 224).
+inline int n_blocks(int B) {
+  static int cap = 0;
+  if (cap == 0) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 256;
+    cap = cus * 7 / 8 > 0 ? cus * 7 / 8 : 1;
+  }
+  return B < cap ? B : cap;
+}
 inline int slab_width(const Dims& d, int want_grad) { return want_grad ? S_DWFC + d.KFC : 1; }
 inline bool supported(int T) {
   if (T < 8 || T % 2) return false;   // even T: the channel-interleaved input rows stay 8-byte aligned
