@@ -33,8 +33,9 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ sr
 
 __global__ __launch_bounds__(256) void col2im_kernel(const void* __restrict__ cols, int cd, int B, int H, int W, int C,
                                                      int KH, int KW, int stride, int pad, int OH, int OW,
-                                                     void* __restrict__ dst, int dd, int planar) {
+                                                     void* __restrict__ dst, int dd, int flags) {
   const int K = KH * KW * C;
+  const bool planar = flags & 1, tap_major = flags & 2;
   const int64_t total = (int64_t)B * H * W * C;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % C);
@@ -50,7 +51,9 @@ __global__ __launch_bounds__(256) void col2im_kernel(const void* __restrict__ co
         if (tw < 0 || tw % stride) continue;
         const int ow = tw / stride;
         if (ow >= OW) continue;
-        s += load_as_f32(cols, cd, (((int64_t)b * OH + oh) * OW + ow) * K + (c * KH + kh) * KW + kw);
+        // tap-major columns ((kh,kw) slow, c fast): the lanes of a wave (consecutive c) read consecutive elements
+        const int col = tap_major ? (kh * KW + kw) * C + c : (c * KH + kh) * KW + kw;
+        s += load_as_f32(cols, cd, (((int64_t)b * OH + oh) * OW + ow) * K + col);
       }
     }
     const int64_t di = planar ? (((int64_t)b * C + c) * H + h) * W + w : i;

@@ -146,13 +146,44 @@ class SimnnDiscFn(torch.autograd.Function):
 # ======================================================================================================================
 # ConvTranspose2d / Conv2d as GEMM + patch lowering (channels-last activations)
 # ======================================================================================================================
-def convT_forward(x2d, w, b, ih, iw, stride, pad, dt):
-    """x2d (B*IH*IW, Cin) -> y (B*OH*OW, Cout) fp32 channels-last; w is torch's (Cin, Cout, KH, KW)."""
+def _tap_major_weight(w, cache, slot):
+    """(Cin, Cout, KH, KW) -> (Cin, KH*KW*Cout) copy: the GEMM then writes its columns in (kh, kw, cout) order, which
+    col2im reads coalesced (torch's order costs a 64-byte stride per lane there).
+
+    ``cache`` is a dict owned by whoever owns the weight (a trainer, a module): entry ``slot`` holds
+    (storage address, version, copy) and is refreshed in place when the weight changed, so the copy's storage is
+    stable under graph replay.  Without a cache the copy is rebuilt on every call."""
+    cin, cout, kh, kw = w.shape
+    wc = w.detach().contiguous()
+
+    def build(out=None):     # (Cin, Cout, KH*KW) -> (Cin, KH*KW, Cout): gdm_permute_pc per input channel
+        return ops.permute_pc(wc, cin, cout, kh * kw, out=out).view(cin, kh * kw * cout)
+    if cache is None:
+        return build()
+    hit = cache.get(slot)
+    if hit is not None and hit[0] == w.data_ptr() and hit[1] == w._version and hit[2].numel() == w.numel():
+        return hit[2]
+    if hit is not None and hit[2].numel() == w.numel():
+        wp = build(out=hit[2].view(cin, kh * kw, cout))
+    else:
+        if torch.cuda.is_current_stream_capturing():
+            raise ops.GdmError("a ConvTranspose2d weight was first seen inside a graph capture: run one eager step first")
+        wp = build()
+    cache[slot] = (w.data_ptr(), w._version, wp)
+    return wp
+
+
+def convT_forward(x2d, w, b, ih, iw, stride, pad, dt, cache=None, slot=0):
+    """x2d (B*IH*IW, Cin) -> y (B*OH*OW, Cout) fp32 channels-last; w is torch's (Cin, Cout, KH, KW).
+    cache / slot: see _tap_major_weight."""
     cin, cout, kh, kw = w.shape
     oh = (ih - 1) * stride - 2 * pad + kh
     ow = (iw - 1) * stride - 2 * pad + kw
-    cols = ops.gemm(x2d, w.view(cin, cout * kh * kw), compute=dt, out_dtype=F32)
-    y = ops.col2im(cols, b=b, h=oh, w=ow, c=cout, kh=kh, kw=kw, stride=stride, pad=pad, oh=ih, ow=iw, out_dtype=F32)
+    tap_major = cout >= 16               # with few output channels torch's order is already the contiguous one
+    w2d = _tap_major_weight(w, cache, slot) if tap_major else w.view(cin, cout * kh * kw)
+    cols = ops.gemm(x2d, w2d, compute=dt, out_dtype=F32)
+    y = ops.col2im(cols, b=b, h=oh, w=ow, c=cout, kh=kh, kw=kw, stride=stride, pad=pad, oh=ih, ow=iw, out_dtype=F32,
+                   tap_major=tap_major)
     return y.view(b * oh * ow, cout), oh, ow
 
 
@@ -175,7 +206,7 @@ def convT_backward(dy2d, x2d, w, b, ih, iw, oh, ow, stride, pad, dt, need_dx=Tru
 _G_GEOM = ((1, 0), (2, 1), (2, 1), (1, 0))   # (stride, padding) of conv1..conv4
 
 
-def simnn_gen_forward(noise, ws, bns, training, dt):
+def simnn_gen_forward(noise, ws, bns, training, dt, cache=None):
     """noise (B,100,1,1); ws = 4 ConvTranspose2d weights; bns = 3 x (gamma, beta, rmean, rvar, nbt).
 
     Returns (out (B,1,20,20) fp32, saved).  Activations are channels-last 2-D matrices (B*H*W, C).
@@ -187,7 +218,7 @@ def simnn_gen_forward(noise, ws, bns, training, dt):
     for li in range(4):
         stride, pad = _G_GEOM[li]
         w = ws[li]
-        y, oh, ow = convT_forward(x, w, b, ih, iw, stride, pad, dt)
+        y, oh, ow = convT_forward(x, w, b, ih, iw, stride, pad, dt, cache=cache, slot=li)
         if li < 3:
             gamma, beta, rm, rv, nbt = bns[li]
             out, mean, invstd = ops.bn_act_fwd(y, gamma, beta, rm, rv, nbt, act=ACT_RELU, out_dtype=F32,

@@ -465,13 +465,14 @@ def im2col(src, *, planar, b, h, w, c, kh, kw, stride, pad, out_dtype):
     return cols, oh, ow
 
 
-def col2im(cols, *, b, h, w, c, kh, kw, stride, pad, oh, ow, out_dtype, planar=False):
+def col2im(cols, *, b, h, w, c, kh, kw, stride, pad, oh, ow, out_dtype, planar=False, tap_major=False):
+    """tap_major: the columns of ``cols`` are ordered (kh, kw, c) instead of torch's (c, kh, kw)."""
     _need_gpu(cols)
     assert cols.is_contiguous() and cols.shape == (b * oh * ow, c * kh * kw)
     shape = (b, c, h, w) if planar else (b, h, w, c)
     dst = torch.empty(shape, dtype=_TORCH_DT[out_dtype], device=cols.device)
     _call("gdm_col2im", _p(cols), gdm_dtype(cols), b, h, w, c, kh, kw, stride, pad, oh, ow, _p(dst),
-                                 out_dtype, 1 if planar else 0, _stream())
+                                 out_dtype, (1 if planar else 0) | (2 if tap_major else 0), _stream())
     return dst
 
 

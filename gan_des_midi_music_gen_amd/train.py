@@ -143,6 +143,7 @@ class SimnnTrainer(_TrainerBase):
         self.last_generated = None
         self._prepared = None      # (packed conv2 images, permuted fc1 weight) for the current weights
         self.overlap = overlap
+        self._tm_cache = {}        # tap-major copies of the generator's ConvTranspose2d weights (per weight version)
         self._side = None
         self._graph = None
         self._scratch_grads = None
@@ -215,7 +216,7 @@ class SimnnTrainer(_TrainerBase):
             if side:
                 side[0].wait_stream(main)
             with torch.cuda.stream(side[0] if side else main):
-                generated, gsaved = Fn.simnn_gen_forward(noise, ws, bns, self.gen.training, dt)
+                generated, gsaved = Fn.simnn_gen_forward(noise, ws, bns, self.gen.training, dt, cache=self._tm_cache)
                 keep.append(gsaved)
             self.last_generated = generated
             return generated

@@ -187,7 +187,10 @@ int gdm_dcnn_fused(const float* xa, int bsplit, const float* p0, const float* p1
  * (Cout, Cin*KH*KW) and ConvTranspose2d weights (Cin, Cout*KH*KW) are GEMM operands in place.                       */
 int gdm_im2col(const void* src, int src_dtype, int src_planar, int B, int H, int W, int C, int KH, int KW,
                int stride, int pad, int OH, int OW, void* cols, int cols_dtype, void* stream);
-/* dst[b,h,w,c] = sum over (oh,ow,kh,kw) with oh*stride-pad+kh==h, ow*stride-pad+kw==w of cols[(b,oh,ow),(c,kh,kw)] */
+/* dst[b,h,w,c] = sum over (oh,ow,kh,kw) with oh*stride-pad+kh==h, ow*stride-pad+kw==w of cols[(b,oh,ow),(c,kh,kw)].
+ * dst_planar: bit 0 = write (B,C,H,W) instead of channels-last; bit 1 = the columns of `cols` are ordered (kh,kw,c)
+ * (tap-major: what a GEMM with the weight permuted to (Cin, KH, KW, Cout) produces -- coalesced reads) instead of
+ * torch's (c,kh,kw).                                                                                               */
 int gdm_col2im(const void* cols, int cols_dtype, int B, int H, int W, int C, int KH, int KW, int stride, int pad,
                int OH, int OW, void* dst, int dst_dtype, int dst_planar, void* stream);
 
