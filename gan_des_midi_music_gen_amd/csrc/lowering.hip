@@ -41,16 +41,18 @@ __global__ __launch_bounds__(256) void col2im_kernel(const void* __restrict__ co
     const int c = (int)(i % C);
     const int w = (int)((i / C) % W), h = (int)((i / ((int64_t)C * W)) % H), b = (int)(i / ((int64_t)C * W * H));
     float s = 0.f;
-    for (int kh = 0; kh < KH; ++kh) {
-      const int th = h + pad - kh;
-      if (th < 0 || th % stride) continue;
-      const int oh = th / stride;
-      if (oh >= OH) continue;
-      for (int kw = 0; kw < KW; ++kw) {
-        const int tw = w + pad - kw;
-        if (tw < 0 || tw % stride) continue;
-        const int ow = tw / stride;
-        if (ow >= OW) continue;
+    // only the taps that can hit this output: kh = (h + pad) mod stride, + stride, ... with 0 <= oh < OH (a stride-2
+    // 4x4 kernel has 2x2 of them, not 16: the kernel is bound by this index arithmetic, not by memory)
+    const int hp = h + pad, wp = w + pad;
+    int kh0 = hp % stride, kw0 = wp % stride;
+    const int kh_min = hp - (OH - 1) * stride, kw_min = wp - (OW - 1) * stride;
+    if (kh_min > kh0) kh0 += (kh_min - kh0 + stride - 1) / stride * stride;
+    if (kw_min > kw0) kw0 += (kw_min - kw0 + stride - 1) / stride * stride;
+    const int kh1 = min(KH - 1, hp), kw1 = min(KW - 1, wp);
+    for (int kh = kh0; kh <= kh1; kh += stride) {
+      const int oh = (hp - kh) / stride;
+      for (int kw = kw0; kw <= kw1; kw += stride) {
+        const int ow = (wp - kw) / stride;
         // tap-major columns ((kh,kw) slow, c fast): the lanes of a wave (consecutive c) read consecutive elements
         const int col = tap_major ? (kh * KW + kw) * C + c : (c * KH + kh) * KW + kw;
         s += load_as_f32(cols, cd, (((int64_t)b * OH + oh) * OW + ow) * K + col);
