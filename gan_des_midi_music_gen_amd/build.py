@@ -15,7 +15,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
          # MFMA results straight into VGPRs: every kernel here post-processes its accumulators with VALU code and none
          # needs more than 256 registers, so the AGPR form only adds v_accvgpr_read/write traffic (5-15 % of the VALU
          # instructions of the issue-bound conv kernels)
-         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+         # no NaN handling in the arithmetic: without it every MFMA result that reaches an fmaxf is first
+         # canonicalised (v_max_f32 x, x, x) -- 16 extra VALU per 16 pooled pixels in the issue-bound conv epilogues
+         "-fno-honor-nans"]
 FLAGS += os.environ.get("GDM_HIPCC_FLAGS", "").split()     # experiment switches (-D...), empty for the shipped build
 
 
