@@ -117,13 +117,45 @@ extern "C" int gdm_col2im(const void* cols, int cols_dtype, int B, int H, int W,
   return GDM_OK;
 }
 
+// The same transpose with a 128 (p) x 32 (c) tile: the writes along p are 512 contiguous bytes per channel row (fp32)
+// instead of 128 -- the large fc1 weight / weight-gradient permutes are bandwidth-bound and DRAM likes long runs.
+__global__ __launch_bounds__(256) void permute_pc_wide_kernel(const void* __restrict__ src, int sd, int P, int C,
+                                                              void* __restrict__ dst, int dd) {
+  __shared__ float tile[128][33];
+  const int t = threadIdx.x;
+  const int p0 = blockIdx.x * 128, c0 = blockIdx.y * 32, b = blockIdx.z;
+  const int64_t base = (int64_t)b * P * C;
+  {
+    const int tx = t & 31, ty = t >> 5;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = p0 + ty + 8 * i, c = c0 + tx;
+      tile[ty + 8 * i][tx] = (p < P && c < C) ? load_as_f32(src, sd, base + (int64_t)p * C + c) : 0.f;
+    }
+  }
+  __syncthreads();
+  {
+    const int tx = t & 127, ty = t >> 7;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = c0 + ty + 2 * i, p = p0 + tx;
+      if (p < P && c < C) store_from_f32(dst, dd, base + (int64_t)c * P + p, tile[tx][ty + 2 * i]);
+    }
+  }
+}
+
 extern "C" int gdm_permute_pc(const void* src, int src_dtype, int B, int P, int C, void* dst, int dst_dtype,
                               void* stream) {
   GDM_REQUIRE(src && dst && B > 0 && P > 0 && C > 0 && gdm_dtype_ok(src_dtype) && gdm_dtype_ok(dst_dtype),
               "gdm_permute_pc: bad arguments");
   GDM_REQUIRE(B <= 65535 && (C + 31) / 32 <= 65535, "gdm_permute_pc: extent too large");
-  hipLaunchKernelGGL(permute_pc_kernel, dim3((P + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, src,
-                     src_dtype, P, C, dst, dst_dtype);
+  if (P >= 512) {
+    hipLaunchKernelGGL(permute_pc_wide_kernel, dim3((P + 127) / 128, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream,
+                       src, src_dtype, P, C, dst, dst_dtype);
+  } else {
+    hipLaunchKernelGGL(permute_pc_kernel, dim3((P + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, src,
+                       src_dtype, P, C, dst, dst_dtype);
+  }
   GDM_LAUNCH_OK("gdm_permute_pc");
   return GDM_OK;
 }
