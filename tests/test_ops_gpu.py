@@ -246,7 +246,8 @@ def _disc_trunk_ref(x, w1, b1, w2, b2):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
-@pytest.mark.parametrize("b,h,w", [(2, 128, 216), (3, 128, 256), (2, 16, 24), (1, 10, 300), (2, 22, 30)])
+@pytest.mark.parametrize("b,h,w", [(2, 128, 216), (3, 128, 256), (2, 16, 24), (1, 10, 300), (2, 22, 30),
+                                   (1, 3, 4), (2, 31, 65), (1, 64, 130), (3, 12, 258), (1, 9, 513)])
 def test_simnn_conv_trunk_forward_backward(dt, b, h, w):
     g = torch.Generator().manual_seed(h * w + b)
     x = (torch.randn(b, h, w, generator=g) * 18 - 35).clamp(-80, 30)
