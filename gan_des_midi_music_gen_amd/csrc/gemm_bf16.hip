@@ -161,8 +161,13 @@ __global__ __launch_bounds__(NT) void gemm_bf16_fast(GemmArgs g) {
   if (outer >= NTl * g.split_k) return;
   const int nt = outer % NTl, zs = outer / NTl;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int kbeg = zs * g.k_per_split;
-  const int kend = min(g.K, kbeg + g.k_per_split);
+  // split-K slices are INTERLEAVED k tiles (slice z takes tiles z, z + split_k, ...), not contiguous ranges: the
+  // workgroups of one output tile run side by side, so together they sweep each operand row contiguously and a DRAM
+  // page is used up while it is open (with contiguous slices every workgroup pulls 128-byte pieces from pages of its
+  // own, 128 KB apart per row).  The slab sum is the same set of products in a different, still fixed, order.
+  const int kstep = KT * g.split_k;
+  const int kbeg = zs * KT;
+  const int kend = g.K;
   const int64_t lda = A_KMAJ ? g.sam : g.sak;
   const int64_t ldb = B_KMAJ ? g.sbn : g.sbk;
   // whole-operand descriptors (sizes checked < 2 GiB on the host)
@@ -203,31 +208,31 @@ __global__ __launch_bounds__(NT) void gemm_bf16_fast(GemmArgs g) {
       stage_store<TA, KT>(xa, la, As);         // waits for THIS stage's loads only: the other stage's were issued later
       stage_store<TB, KT>(xb, lb, Bs);
       __syncthreads();                         // one barrier per tile: the other LDS buffer is what laggards still read
-      stage_load<TA, KT, A_KMAJ>(xa, la, ra, lda, k0 + 2 * KT, kend);   // two tiles ahead, always issued (zeros past kend)
-      stage_load<TB, KT, B_KMAJ>(xb, lb, rb, ldb, k0 + 2 * KT, kend);
+      stage_load<TA, KT, A_KMAJ>(xa, la, ra, lda, k0 + 2 * kstep, kend);   // two tiles ahead, always issued (zeros past kend)
+      stage_load<TB, KT, B_KMAJ>(xb, lb, rb, ldb, k0 + 2 * kstep, kend);
       multiply(As, Bs);
     };
     stage_load<TA, KT, A_KMAJ>(sa[0], la, ra, lda, kbeg, kend);
     stage_load<TB, KT, B_KMAJ>(sb[0], lb, rb, ldb, kbeg, kend);
-    stage_load<TA, KT, A_KMAJ>(sa[1], la, ra, lda, kbeg + KT, kend);
-    stage_load<TB, KT, B_KMAJ>(sb[1], lb, rb, ldb, kbeg + KT, kend);
+    stage_load<TA, KT, A_KMAJ>(sa[1], la, ra, lda, kbeg + kstep, kend);
+    stage_load<TB, KT, B_KMAJ>(sb[1], lb, rb, ldb, kbeg + kstep, kend);
     // tiles are taken in pairs so that both register stages have a fixed place in the loop; an odd tail tile is zeros
-    for (int k0 = kbeg; k0 < kend; k0 += 2 * KT) {
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * kstep) {
       tile(sa[0], sb[0], smem, k0);
-      tile(sa[DEPTH - 1], sb[DEPTH - 1], smem + 2 * IMG * (DEPTH - 1), k0 + KT);
+      tile(sa[DEPTH - 1], sb[DEPTH - 1], smem + 2 * IMG * (DEPTH - 1), k0 + kstep);
     }
   } else {
     __bf16* As = smem;
     __bf16* Bs = smem + IMG;
     stage_load<TA, KT, A_KMAJ>(sa[0], la, ra, lda, kbeg, kend);
     stage_load<TB, KT, B_KMAJ>(sb[0], lb, rb, ldb, kbeg, kend);
-    for (int k0 = kbeg; k0 < kend; k0 += KT) {
+    for (int k0 = kbeg; k0 < kend; k0 += kstep) {
       __syncthreads();                         // previous tile's fragment reads are done
       stage_store<TA, KT>(sa[0], la, As);
       stage_store<TB, KT>(sb[0], lb, Bs);
       __syncthreads();
-      stage_load<TA, KT, A_KMAJ>(sa[0], la, ra, lda, k0 + KT, kend);    // next tile, always issued (zeros past kend)
-      stage_load<TB, KT, B_KMAJ>(sb[0], lb, rb, ldb, k0 + KT, kend);
+      stage_load<TA, KT, A_KMAJ>(sa[0], la, ra, lda, k0 + kstep, kend);    // next tile, always issued (zeros past kend)
+      stage_load<TB, KT, B_KMAJ>(sb[0], lb, rb, ldb, k0 + kstep, kend);
       multiply(As, Bs);
     }
   }
