@@ -121,15 +121,9 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
 }
 
 // ------------------------------------------------------------------------------------------------- batch norm fwd
-// Stage 1: per (row-chunk, column) Welford triple (count, mean, M2); lanes = 64 consecutive columns, the 4 waves
-// of a workgroup interleave rows and are merged in wave order (Chan's formula).
+// Stage 1: per (row-chunk, column) Welford triple (count, mean, M2); lanes = consecutive columns, the 4 waves of a
+// workgroup interleave rows and are merged in wave order (Chan's formula).
 struct Welford { float n, mean, m2; };
-__device__ __forceinline__ void welford_add(Welford& a, float x) {
-  a.n += 1.f;
-  const float d = x - a.mean;
-  a.mean += d / a.n;
-  a.m2 += d * (x - a.mean);
-}
 __device__ __forceinline__ void welford_merge(Welford& a, const Welford& b) {
   if (b.n == 0.f) return;
   const float n = a.n + b.n;
@@ -139,22 +133,47 @@ __device__ __forceinline__ void welford_merge(Welford& a, const Welford& b) {
   a.n = n;
 }
 
+// A thread's share of a chunk is at most a few dozen values: it keeps SHIFTED sums (shift = its first value, so the
+// sums stay small whatever the channel's mean is) with eight loads in flight, and converts them to a Welford triple
+// once.  `CW` = lanes per row (power of two >= min(C, 64)): with fewer than 64 channels a wave covers 64 / CW rows per
+// load, so no lane idles.
+__device__ __forceinline__ Welford welford_from_shifted(float n, float shift, float s, float ss) {
+  Welford a{n, 0.f, 0.f};
+  if (n > 0.f) {
+    a.mean = shift + s / n;
+    a.m2 = fmaxf(ss - s * (s / n), 0.f);
+  }
+  return a;
+}
+
 __global__ __launch_bounds__(256) void bn_partial_stats(const float* __restrict__ y, int rows, int C, int chunk_rows,
-                                                        float* __restrict__ ws) {
+                                                        int CW, float* __restrict__ ws) {
   __shared__ Welford sh[4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  const int rpl = 64 / CW;                                   // rows per wave-wide load
+  const int c = blockIdx.x * 64 + (lane & (CW - 1)), sub = lane / CW;
   const int r0 = blockIdx.y * chunk_rows, r1 = min(rows, r0 + chunk_rows);
-  Welford a{0.f, 0.f, 0.f};
-  if (c < C)
-    for (int r = r0 + wv; r < r1; r += 4) welford_add(a, y[(int64_t)r * C + c]);
-  sh[wv][lane] = a;
+  const int step = 4 * rpl;                                  // the 4 waves interleave row groups
+  float n = 0.f, shift = 0.f, s = 0.f, ss = 0.f;
+  if (c < C) {
+    int r = r0 + wv * rpl + sub;
+    if (r < r1) shift = y[(int64_t)r * C + c];
+    for (; r + 7 * step < r1; r += 8 * step) {
+      float x[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = y[(int64_t)(r + q * step) * C + c];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const float d = x[q] - shift; s += d; ss += d * d; }
+      n += 8.f;
+    }
+    for (; r < r1; r += step) { const float d = y[(int64_t)r * C + c] - shift; s += d; ss += d * d; n += 1.f; }
+  }
+  sh[wv][lane] = welford_from_shifted(n, shift, s, ss);
   __syncthreads();
-  if (wv == 0 && c < C) {
-    Welford t = sh[0][lane];
-    welford_merge(t, sh[1][lane]);
-    welford_merge(t, sh[2][lane]);
-    welford_merge(t, sh[3][lane]);
+  if (wv == 0 && sub == 0 && c < C) {
+    Welford t{0.f, 0.f, 0.f};
+    for (int w = 0; w < 4; ++w)
+      for (int q = 0; q < rpl; ++q) welford_merge(t, sh[w][q * CW + lane]);       // fixed order
     float* o = ws + ((int64_t)blockIdx.y * C + c) * 3;
     o[0] = t.n; o[1] = t.mean; o[2] = t.m2;
   }
@@ -172,10 +191,16 @@ __global__ __launch_bounds__(1024) void bn_finalize(const float* __restrict__ ws
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
   Welford t{0.f, 0.f, 0.f};
   if (c < C)
-    for (int k = wv; k < chunks; k += 16) {
-      const float* o = ws + ((int64_t)k * C + c) * 3;
-      Welford b{o[0], o[1], o[2]};
-      welford_merge(t, b);
+    for (int k = wv; k < chunks; k += 16 * 8) {                 // eight triples in flight, merged in chunk order
+      Welford b[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int kk = k + 16 * q;
+        const float* o = ws + ((int64_t)min(kk, chunks - 1) * C + c) * 3;
+        b[q] = Welford{kk < chunks ? o[0] : 0.f, o[1], o[2]};
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) welford_merge(t, b[q]);
     }
   part[wv][lane] = t;
   __syncthreads();
@@ -327,8 +352,8 @@ __global__ __launch_bounds__(256) void cast_kernel(const void* __restrict__ src,
 }
 
 inline int row_chunks(int rows) {
-  int c = (rows + 63) / 64;          // >= 64 rows per chunk (16 per wave)
-  return c < 1 ? 1 : (c > 256 ? 256 : c);
+  int c = (rows + 255) / 256;        // >= 256 rows per chunk; at most 64 chunks (one round of the finalize kernel)
+  return c < 1 ? 1 : (c > 64 ? 64 : c);
 }
 inline unsigned grid_for(int64_t total) {
   int64_t b = (total + 255) / 256;
@@ -403,7 +428,9 @@ extern "C" int gdm_bn_act_fwd(const float* y, int rows, int channels, const floa
       return GDM_EWORKSPACE;
     }
     const int chunk_rows = (rows + chunks - 1) / chunks;
-    hipLaunchKernelGGL(bn_partial_stats, dim3((C + 63) / 64, chunks), dim3(256), 0, s, y, rows, C, chunk_rows,
+    int cw = 64;
+    while (cw / 2 >= C && cw > 1) cw /= 2;                      // lanes per row: power of two >= min(C, 64)
+    hipLaunchKernelGGL(bn_partial_stats, dim3((C + 63) / 64, chunks), dim3(256), 0, s, y, rows, C, chunk_rows, cw,
                        (float*)workspace);
     hipLaunchKernelGGL(bn_finalize, dim3((C + 63) / 64), dim3(1024), 0, s, (const float*)workspace, chunks, rows, C,
                        momentum, eps, running_mean, running_var, num_batches_tracked, save_mean, save_invstd);

@@ -188,7 +188,8 @@ def test_adam_matches_torch_optim():
 
 
 @pytest.mark.parametrize("rows,c,act", [(16, 256, ACT_SIGMOID), (4, 4096, ACT_SIGMOID), (256, 20, ACT_SIGMOID),
-                                        (16 * 64, 64, ACT_RELU), (5000, 32, ACT_RELU)])
+                                        (16 * 64, 64, ACT_RELU), (5000, 32, ACT_RELU), (65536, 32, ACT_RELU),
+                                        (4096, 128, ACT_RELU), (777, 8, ACT_RELU)])
 def test_batchnorm_act_fwd_bwd(rows, c, act):
     g = torch.Generator().manual_seed(rows + c)
     y = torch.randn(rows, c, generator=g) * 2 + 0.5

@@ -29,8 +29,8 @@ print(f"graph, overlap            : {timed(build(True)):8.1f} us/step")
 print(f"graph, single stream      : {timed(build(False)):8.1f} us/step")
 orig_gen = Fn.simnn_gen_forward
 cache = {}
-def fake_gen(noise, ws, bns, training, dt):
-    if "o" not in cache: cache["o"] = orig_gen(noise, ws, bns, training, dt)
+def fake_gen(noise, ws, bns, training, dt, **kw):
+    if "o" not in cache: cache["o"] = orig_gen(noise, ws, bns, training, dt, **kw)
     return cache["o"]
 Fn.simnn_gen_forward = fake_gen
 print(f"graph, overlap, no G fwd  : {timed(build(True)):8.1f} us/step")
