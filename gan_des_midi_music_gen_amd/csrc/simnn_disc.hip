@@ -114,7 +114,7 @@ __device__ __forceinline__ void buf_store2(rsrc_t r, uint32_t off, uint32_t v) {
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, int B, int H, int W, int H1,
-                                                        int W1, int n_units, T* __restrict__ p1,
+                                                        int W1, int n_rows, T* __restrict__ p1,
                                                         uint64_t* __restrict__ code1) {
   const int t = threadIdx.x, l = t & 63, lr = l & 15, lg = l >> 4;
   // the wave index is uniform: keep everything derived from it in scalar registers
@@ -132,19 +132,32 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
   for (int p = 0; p < 4; ++p) loff[p] = (uint32_t)(((r_lo + (p >> 1)) * W + c_lo + (p & 1)) * 4);   // may wrap: added to base
 
-  // wave w takes units w, w + n_waves, ... (all waves sweep the tensors as one front); a unit's (seg, ph, b) is
-  // carried from step to step with scalar carries, never re-divided
-  struct Pos { int seg, ph, b; };
-  const int dseg = n_waves % upr, dph = (n_waves / upr) % H1, db = n_waves / (upr * H1);
-  auto advance = [&](Pos& q) {
-    q.seg += dseg; q.ph += dph; q.b += db;
-    if (q.seg >= upr) { q.seg -= upr; ++q.ph; }
-    if (q.ph >= H1) { q.ph -= H1; ++q.b; }
-  };
-  auto load = [&](const Pos& q, float (&xv)[4]) {
+  // Work is dealt by pooled ROW: wave w takes rows w, w + n_waves, ... of the (b, ph) row space and walks each row's
+  // units left to right, so the per-unit bookkeeping is "seg += DEPTH, compare" in scalar registers; everything that
+  // depends on the row (base offsets, row-interior flag, validity) is recomputed only when a slot moves to its next
+  // row, behind a scalar branch.  (Per-unit position arithmetic with carries cost ~100 SALU instructions per unit --
+  // more than the unit's VALU work; the CU's single scalar unit was the limiter.)
+  struct Slot { int seg, ph, b; uint32_t xrow, pixrow; bool interior, valid; };
+  const int dph = n_waves % H1, db = n_waves / H1;
+  auto set_row = [&](Slot& q) {
     const int b = min(q.b, B - 1);                           // past the end: re-read the last image (stores are dropped)
-    const uint32_t base = (uint32_t)(((b * H + 2 * q.ph) * W + 32 * q.seg) * 4);
-    if (q.ph > 0 && 2 * q.ph + 1 < H && q.seg > 0 && 32 * q.seg + 32 < W) {      // interior unit (scalar test)
+    q.xrow = (uint32_t)(((b * H + 2 * q.ph) * W) * 4);
+    q.pixrow = (uint32_t)((b * H1 + q.ph) * W1);
+    q.interior = q.ph > 0 && 2 * q.ph + 1 < H;
+    q.valid = q.b < B;
+  };
+  auto step = [&](Slot& q, int n) {
+    q.seg += n;
+    while (q.seg >= upr) {
+      q.seg -= upr;
+      q.ph += dph; q.b += db;
+      if (q.ph >= H1) { q.ph -= H1; ++q.b; }
+      set_row(q);
+    }
+  };
+  auto load = [&](const Slot& q, float (&xv)[4]) {
+    const uint32_t base = q.xrow + 128u * (uint32_t)q.seg;
+    if (q.interior && q.seg > 0 && 32 * q.seg + 32 < W) {    // interior unit (scalar test)
 #pragma unroll
       for (int p = 0; p < 4; ++p) xv[p] = buf_load4(xr, base + loff[p]);
       return;
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
     for (int p = 0; p < 4; ++p) xv[p] = buf_load4(xr, (rok[p >> 1] && cok[p & 1]) ? base + loff[p] : BUF_OOB);
   };
-  auto finish = [&](const Pos& q, bool valid, const float (&xv)[4]) {
+  auto finish = [&](const Slot& q, const float (&xv)[4]) {
     f32x4 acc[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, xv[p], b4, 0, 0, 0);
@@ -174,8 +187,8 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       field |= (m > 0.f ? 1u : 0u) << (8 + r);
     }
     const int pw = 16 * q.seg + lr;
-    const uint32_t pix = (uint32_t)((q.b * H1 + q.ph) * W1 + pw);
-    const bool ok = valid && pw < W1;
+    const uint32_t pix = q.pixrow + (uint32_t)pw;
+    const bool ok = q.valid && pw < W1;
     if constexpr (sizeof(T) == 2) {
       bf16x4 h;
 #pragma unroll
@@ -186,25 +199,24 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
     buf_store2(cr, ok ? pix * 8u + 2u * lg : BUF_OOB, field);
   };
-  int u = wave;
-  if (u >= n_units) return;
+  if (wave >= n_rows) return;
   // DEPTH units in flight per wave; every trip issues the same loads and stores (units past the end re-read valid
   // memory and their stores are dropped), so the waits between them are exact counts.  The sched_barriers keep the
   // compiler from sinking the refill loads below the next unit's MFMAs (which would expose their latency again).
   constexpr int DEPTH = 4;
-  Pos q[DEPTH];
+  Slot q[DEPTH];
   float xv[DEPTH][4];
-  q[0] = {u % upr, (u / upr) % H1, u / (upr * H1)};
+  q[0].seg = 0; q[0].ph = wave % H1; q[0].b = wave / H1;
+  set_row(q[0]);
 #pragma unroll
-  for (int d = 1; d < DEPTH; ++d) { q[d] = q[d - 1]; advance(q[d]); }
+  for (int d = 1; d < DEPTH; ++d) { q[d] = q[d - 1]; step(q[d], 1); }
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) load(q[d], xv[d]);
-  for (; u < n_units; u += DEPTH * n_waves) {
+  while (q[0].valid) {                          // slot 0 is the earliest unit of the trip
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      finish(q[d], u + d * n_waves < n_units, xv[d]);
-#pragma unroll
-      for (int e = 0; e < DEPTH; ++e) advance(q[d]);
+      finish(q[d], xv[d]);
+      step(q[d], DEPTH);
       load(q[d], xv[d]);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -1376,11 +1388,11 @@ extern "C" int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* 
   const int H1 = (H + 1) / 2, W1 = (W + 1) / 2;
   GDM_REQUIRE((int64_t)B * H1 * W1 * 64 < ((int64_t)1 << 31) && (int64_t)B * H * W * 4 < ((int64_t)1 << 31),
               "gdm_simnn_conv1_fwd: batch of %d %dx%d inputs exceeds 2 GiB per tensor", B, H, W);
-  const int64_t n_units = (int64_t)B * H1 * ((W1 + 15) / 16);          // 16 pooled pixels of one pooled row each
-  int64_t blocks = (n_units + 7) / 8;                                    // >= 2 units per wave, 4 waves per workgroup
+  const int64_t n_rows = (int64_t)B * H1;                                // a wave walks whole pooled rows
+  int64_t blocks = (n_rows + 3) / 4;                                     // 4 waves per workgroup
   if (blocks > 2048) blocks = 2048;                                      // persistent: 8 workgroups per CU
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                                       x, w, bias, B, H, W, H1, W1, (int)n_units, (T*)p1, code1));
+                                       x, w, bias, B, H, W, H1, W1, (int)n_rows, (T*)p1, code1));
   GDM_LAUNCH_OK("gdm_simnn_conv1_fwd");
   return GDM_OK;
 }
