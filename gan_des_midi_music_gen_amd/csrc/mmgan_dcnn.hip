@@ -441,8 +441,12 @@ inline int n_blocks(int B) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       cus = 256;
     cap = cus * 7 / 8 > 0 ? cus * 7 / 8 : 1;
+    if (const char* e = getenv("GDM_DCNN_CAP")) { if (atoi(e) > 0) cap = atoi(e); }     // experiments only
   }
-  return B < cap ? B : cap;
+  // the fewest workgroups that finish in the same number of sample rounds (512 samples on 224 workgroups take three
+  // rounds; so do 171, which leaves 85 CUs instead of 32 to the kernels running beside this one)
+  const int rounds = (B + cap - 1) / cap;
+  return (B + rounds - 1) / rounds;
 }
 inline int slab_width(const Dims& d, int want_grad) { return want_grad ? S_DWFC + d.KFC : 1; }
 inline bool supported(int T) {
