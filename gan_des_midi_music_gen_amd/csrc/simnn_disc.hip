@@ -158,8 +158,14 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
   auto load = [&](const Slot& q, float (&xv)[4]) {
     const uint32_t base = q.xrow + 128u * (uint32_t)q.seg;
     if (q.interior && q.seg > 0 && 32 * q.seg + 32 < W) {    // interior unit (scalar test)
+      // the lane's 2x2 patch as two 8-byte loads (4-byte aligned): memory instructions, not bytes, are what the
+      // address unit charges for
 #pragma unroll
-      for (int p = 0; p < 4; ++p) xv[p] = buf_load4(xr, base + loff[p]);
+      for (int dy = 0; dy < 2; ++dy) {
+        const uint64_t two = buf_load8(xr, base + loff[2 * dy]);
+        xv[2 * dy] = __builtin_bit_cast(float, (uint32_t)two);
+        xv[2 * dy + 1] = __builtin_bit_cast(float, (uint32_t)(two >> 32));
+      }
       return;
     }
     const int row0 = 2 * q.ph + r_lo, col0 = 32 * q.seg + c_lo;
