@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Copy the summaries tools/profile_round.sh (and tools/pmc_ops.sh) left under gpurun_out/ into profiles/ (tracked).
+Run in the container after the gpurun call: python tools/collect_profiles.py [round-tag, default r01]."""
+import glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out, prof = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+
+
+def newest(pattern):
+    files = glob.glob(os.path.join(out, pattern))
+    return max(files, key=os.path.getmtime) if files else None
+
+
+def copy(src, name):
+    if src and os.path.exists(src):
+        shutil.copyfile(src, os.path.join(prof, name))
+        print(f"{os.path.relpath(src, ROOT)} -> profiles/{name}")
+    else:
+        print(f"missing: {name}")
+
+
+copy(newest("final_simnn/*/*_kernel_stats.csv"), f"{tag}_simnn_kernel_stats.csv")
+copy(newest("final_simnn_eager/*/*_kernel_stats.csv"), f"{tag}_simnn_eager_kernel_stats.csv")
+copy(newest("final_mmgan/*/*_kernel_stats.csv"), f"{tag}_mmgan_kernel_stats.csv")
+copy(os.path.join(out, "hbm_traffic.json"), f"{tag}_simnn_b256_bf16_hbm_traffic.json")
+copy(os.path.join(out, "pmc_sq.txt"), f"{tag}_simnn_b256_bf16_pmc_sq.txt")
+copy(os.path.join(out, "step_breakdown.txt"), f"{tag}_simnn_b256_bf16_step_breakdown.txt")
+copy(os.path.join(out, "bench_default.json"), f"{tag}_bench_default.json")
+copy(os.path.join(out, "bench_mmgan.json"), f"{tag}_bench_mmgan.json")
+copy(os.path.join(out, "pmc_ops_summary.txt"), f"{tag}_conv_kernels_b512_pmc_sq.txt")
+
+# bench.py reads the dominant kernel's measured HBM bytes per launch from profiles/traffic.json
+src = os.path.join(out, "hbm_traffic.json")
+if os.path.exists(src):
+    d = json.load(open(src))
+    fused = [v for k, v in d.items() if "conv2_bwd_data_kernel" in k and "true" in k]
+    if fused:
+        t = {"simnn_bf16": int(fused[0]["hbm_bytes_per_launch"]),
+             "_source": f"profiles/{tag}_simnn_b256_bf16_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                        "passes, FETCH_SIZE x2 on gfx950), average over the 2B and B launches of one faithful iteration; "
+                        "kernel: conv2_bwd_data_kernel<FUSE>"}
+        json.dump(t, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
+        print("profiles/traffic.json:", t["simnn_bf16"])
