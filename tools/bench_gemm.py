@@ -26,8 +26,11 @@ def main():
     res["fc1 fwd  (B,K)x(K,128)"] = (timeit(lambda: ops.gemm(flat, wf1p.t(), bias_n=bf1, act=ACT_RELU, compute=BF16)), (B * K * 2 + 128 * K * 2) / 1e6)
     res["fc1 dW   (128,B)x(B,K)"] = (timeit(lambda: ops.gemm(dh1.t(), flat, compute=BF16)), (B * K * 2 + 128 * K * 4) / 1e6)
     res["fc1 dX   (B,128)x(128,K)"] = (timeit(lambda: ops.gemm(dh1, wf1p, compute=BF16, out_dtype=BF16)), (B * K * 2 + 128 * K * 2) / 1e6)
+    dh16 = dh1.to(torch.bfloat16)
+    res["fc1 dW, bf16 dh"] = (timeit(lambda: ops.gemm(dh16.t(), flat, compute=BF16)), (B * K * 2 + 128 * K * 4) / 1e6)
+    res["fc1 dX, bf16 dh"] = (timeit(lambda: ops.gemm(dh16, wf1p, compute=BF16, out_dtype=BF16)), (B * K * 2 + 128 * K * 2) / 1e6)
     for k, ((med, mn), mb) in res.items():
-        print(f"{k:28s} B={B} median {med:8.1f} us  min {mn:8.1f} us   {mb:6.1f} MB -> {mb / med * 1e-6 * 1e6 / 1e3:5.2f} TB/s")
+        print(f"{k:28s} B={B} median {med:8.1f} us  min {mn:8.1f} us   {mb:6.1f} MB -> {mb / med:5.2f} TB/s")
 
 if __name__ == "__main__":
     main()
