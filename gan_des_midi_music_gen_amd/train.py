@@ -252,16 +252,25 @@ class SimnnTrainer(_TrainerBase):
         # weights changed: rebuild the packed conv2 images and the permuted fc1 operand once, use them for the G-step
         # forward below AND for the next iteration's D-step forward
         # (refreshed in place: they are cross-iteration state, so their storage must be stable under graph replay)
-        Fn.simnn_disc_prepare(w2, wf1, dt, out=self._prepared)
+        # -- on a side stream: conv1 of the G-step forward does not read them, so the 50 MB permute/cast pass runs beside it
+        if side:
+            side[1].wait_stream(main)
+        with torch.cuda.stream(side[1] if side else main):
+            Fn.simnn_disc_prepare(w2, wf1, dt, out=self._prepared)
         # --- "generator" step (SIMNN.py:322-331): D forward on fake with the updated weights, label 1.0
-        hid_g, saved_g = Fn.simnn_disc_features(fake, w1, b1, pack, b2, wf1p, bf1, dt)
+        p1g = torch.empty((b, h1, w1s, 16), dtype=adt, device=real.device)
+        code1g = torch.empty((b, h1, w1s), dtype=torch.int64, device=real.device)
+        ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1g, code1g))
+        if side:
+            main.wait_stream(side[1])
+        hid_g, saved_g = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1g, code1g))
         _prob, dh_g, _ = ops.simnn_head(hid_g, wf2, bf2, b, 1.0, 1.0, loss_out=self.loss_g, want_grad=not self.elide)
         if not self.elide:
             # dead values: gen_loss.backward() only fills D's .grad, which the next zero_grad() wipes (SIMNN.py:330,
             # 282); they are computed (faithful mode) into a scratch set of gradient buffers
             if self._scratch_grads is None:
                 self._scratch_grads = [torch.empty_like(g) for g in gv]
-            self._d_backward(saved_g, dh_g, pack, wf1p, self._scratch_grads, None, keep)
+            self._d_backward(saved_g, dh_g, pack, wf1p, self._scratch_grads, (fake, None), keep)
         if side:
             main.wait_stream(side[0])
         # gen_opt.step(): every generator .grad is None -> no-op
