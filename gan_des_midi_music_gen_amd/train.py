@@ -132,6 +132,13 @@ class SimnnTrainer(_TrainerBase):
     discriminator step; fc1's weight gradient and conv2's weight gradient beside the data-gradient chain); all
     branches re-join before the optimizer and before ``step`` returns.  ``capture``/``replay`` record the whole
     iteration (all branches) into one hipGraph for fixed input buffers.
+
+    ``step_pipelined`` is the same iteration scheduled across two calls: the "generator" half of iteration i (the
+    discriminator pass on fake_i with the weights Adam(i) produced, SIMNN.py:322-331) only reads state that nothing
+    modifies until Adam(i+1), so it runs on a stream of its own BESIDE the discriminator step of iteration i+1 (its
+    memory-bound GEMMs fill the issue-bound conv kernels of the other chain and vice versa).  Every iteration still
+    executes exactly the reference's work in the reference's dependency order; ``flush`` runs the half that is
+    still pending.  After ``flush`` all state equals the sequential ``step``'s bit for bit.
     """
 
     def __init__(self, gen, disc, lr=0.00002, betas=(0.5, 0.999), eps=1e-8, compute_dtype=None,
@@ -147,10 +154,13 @@ class SimnnTrainer(_TrainerBase):
         self._side = None
         self._graph = None
         self._scratch_grads = None
+        self._pending_fake = None  # step_pipelined: fake batch whose generator half has not run yet
+        self._prepared_stale = False
 
     def invalidate_weights(self):
         """Call after changing discriminator weights from outside (e.g. load_state_dict)."""
         self._prepared = None
+        self._prepared_stale = False
 
     def _gen_state(self):
         g = self.gen
@@ -161,17 +171,19 @@ class SimnnTrainer(_TrainerBase):
 
     def _streams(self, dev):
         if self._side is None:
-            self._side = [torch.cuda.Stream(dev) for _ in range(2)]
+            self._side = [torch.cuda.Stream(dev) for _ in range(3)]
         return self._side
 
-    def _d_backward(self, saved, dh, pack, wf1p, outs, x_pair, keep):
-        """Discriminator backward below the head: fc1's weight gradient runs beside the data-gradient chain."""
+    def _d_backward(self, saved, dh, pack, wf1p, outs, x_pair, keep, fork=True):
+        """Discriminator backward below the head: fc1's weight gradient runs beside the data-gradient chain
+        (fork=False: everything on the current stream -- a branch of a captured graph must not fork again: a
+        second-level fork crashed hipStreamEndCapture)."""
         dt = self.dt
         x, p1, code1, flat, code2 = saved[:5]
         b = p1.shape[0]
         n, k = wf1p.shape
         main = torch.cuda.current_stream()
-        side = self._streams(p1.device) if self.overlap else None
+        side = self._streams(p1.device) if (self.overlap and fork) else None
         # branch A: fc1 weight gradient (GEMM + permute back to the parameter's flatten order)
         if side:
             side[1].wait_stream(main)
@@ -201,6 +213,8 @@ class SimnnTrainer(_TrainerBase):
         """real (B,H,W) fp32 on the device; noise (B,noise_dim,1,1); fake: (B,H,W) tensor, or a callable
         ``fake(generated (B,1,20,20) device tensor) -> (B,H,W) tensor`` standing in for matrix_to_wav (SIMNN.py:301).
         Returns (disc_loss, gen_loss) as 1-element device tensors (this rank's batch means)."""
+        if self._pending_fake is not None:
+            self.flush()
         dt = self.dt
         w1, b1, w2, b2, wf1, bf1, wf2, bf2 = self.d.views
         gv = self.d.grad_views
@@ -210,6 +224,9 @@ class SimnnTrainer(_TrainerBase):
         side = self._streams(real.device) if self.overlap else None
         keep = []
         ws, bns = self._gen_state()
+        if self._prepared is not None and self._prepared_stale:
+            Fn.simnn_disc_prepare(w2, wf1, dt, out=self._prepared)
+            self._prepared_stale = False
 
         def generator_forward():
             # SIMNN.py:293-296; the output only feeds the (external) bridge -> own stream
@@ -278,23 +295,125 @@ class SimnnTrainer(_TrainerBase):
         del keep
         return self.loss_d, self.loss_g
 
+    # ---- the same iteration, generator half of iteration i beside the discriminator step of iteration i+1 ----------
+    def _generator_half(self, fake, keep):
+        """SIMNN.py:322-331 on the current stream: D forward on fake with the current weights, label 1.0, and (faithful
+        mode) the dead backward into scratch gradient buffers.  Needs fresh ``self._prepared``."""
+        dt = self.dt
+        w1, b1, w2, b2, wf1, bf1, wf2, bf2 = self.d.views
+        pack, wf1p = self._prepared
+        b = fake.shape[0]
+        hid_g, saved_g = Fn.simnn_disc_features(fake, w1, b1, pack, b2, wf1p, bf1, dt)
+        _prob, dh_g, _ = ops.simnn_head(hid_g, wf2, bf2, b, 1.0, 1.0, loss_out=self.loss_g, want_grad=not self.elide)
+        if not self.elide:
+            if self._scratch_grads is None:
+                self._scratch_grads = [torch.empty_like(g) for g in self.d.grad_views]
+            self._d_backward(saved_g, dh_g, pack, wf1p, self._scratch_grads, (fake, None), keep, fork=False)
+        keep.append((hid_g, saved_g, dh_g))
+
+    @torch.no_grad()
+    def step_pipelined(self, real, noise, fake):
+        """Like ``step`` for tensor inputs, but the generator half of THIS iteration is left pending and the pending
+        half of the previous iteration runs beside this iteration's discriminator step.  Returns (disc_loss of this
+        iteration, gen_loss of the previous one) as device tensors; call ``flush`` after the last iteration."""
+        if callable(fake):
+            raise ops.GdmError("step_pipelined needs a tensor for the fake batch (the bridge is host code)")
+        dt = self.dt
+        w1, b1, w2, b2, wf1, bf1, wf2, bf2 = self.d.views
+        gv = self.d.grad_views
+        real = Fn._f32c(real)
+        fake = Fn._f32c(fake.to(real.device))
+        assert fake.shape == real.shape, (fake.shape, real.shape)
+        b, h, w = real.shape
+        main = torch.cuda.current_stream()
+        side = self._streams(real.device) if self.overlap else None
+        keep = []
+        ws, bns = self._gen_state()
+        pending = self._pending_fake
+        if self._prepared is None:
+            self._prepared = Fn.simnn_disc_prepare(w2, wf1, dt)
+            self._prepared_stale = False
+        pack, wf1p = self._prepared
+        if self._scratch_grads is None:
+            self._scratch_grads = [torch.empty_like(g) for g in gv]
+        h1, w1s = (h + 1) // 2, (w + 1) // 2
+        adt = ops.torch_dtype(dt)
+        p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=real.device)
+        code1 = torch.empty((2 * b, h1, w1s), dtype=torch.int64, device=real.device)
+        ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
+        # branches fork after the first main-stream launch (see step)
+        if side:
+            side[0].wait_stream(main)
+        with torch.cuda.stream(side[0] if side else main):
+            generated, gsaved = Fn.simnn_gen_forward(noise, ws, bns, self.gen.training, dt, cache=self._tm_cache)
+            keep.append(gsaved)
+        self.last_generated = generated
+        if self._prepared_stale:
+            # weights changed in the previous call: rebuild the packed conv2 images / permuted fc1 operand beside conv1
+            if side:
+                side[1].wait_stream(main)
+            with torch.cuda.stream(side[1] if side else main):
+                Fn.simnn_disc_prepare(w2, wf1, dt, out=self._prepared)
+            self._prepared_stale = False
+            ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
+            if side:
+                main.wait_stream(side[1])
+        else:
+            ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
+        if pending is not None:
+            # generator half of the previous iteration: reads the weights / prepared operands that stay untouched until
+            # this call's Adam, writes only gen_loss and scratch buffers
+            if side:
+                side[2].wait_stream(main)
+            with torch.cuda.stream(side[2] if side else main):
+                self._generator_half(pending, keep)
+        hid, saved = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1, code1))
+        _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 0.9, 0.1, loss_out=self.loss_d, grad_out=(gv[6], gv[7], gv[5]))
+        self._d_backward(saved, dh, pack, wf1p, gv, (real, fake), keep)
+        if side and pending is not None:
+            main.wait_stream(side[2])
+        self._reduce_and_step()
+        self._prepared_stale = True
+        if side:
+            main.wait_stream(side[0])
+        self._pending_fake = fake
+        self.iterations += 1
+        del keep
+        return self.loss_d, self.loss_g
+
+    @torch.no_grad()
+    def flush(self):
+        """Run the generator half left pending by ``step_pipelined``; returns its gen_loss (device tensor)."""
+        if self._pending_fake is None:
+            return self.loss_g
+        w1, b1, w2, b2, wf1 = self.d.views[:5]
+        if self._prepared_stale:
+            Fn.simnn_disc_prepare(w2, wf1, self.dt, out=self._prepared)
+            self._prepared_stale = False
+        keep = []
+        self._generator_half(self._pending_fake, keep)
+        self._pending_fake = None
+        del keep
+        return self.loss_g
+
     # ---- hipGraph capture of the whole iteration for fixed input buffers -------------------------------------------
-    def capture(self, real, noise, fake):
+    def capture(self, real, noise, fake, pipelined=False):
         """Record one iteration on (real, noise, fake) -- tensors whose storage is re-used for every replay -- into a
         hipGraph.  Not available with a callable bridge or with more than one rank."""
         if callable(fake) or self.world > 1:
             raise ops.GdmError("graph capture needs tensor inputs and a single rank")
         self._static = (Fn._f32c(real), noise, Fn._f32c(fake))
+        fn = self.step_pipelined if pipelined else self.step
         warm = torch.cuda.Stream(real.device)
         warm.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(warm):
             for _ in range(2):
-                self.step(*self._static)
+                fn(*self._static)
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            self.step(*self._static)
+            fn(*self._static)      # pipelined: the captured call finds a pending half and leaves one, like every replay
         return self._graph
 
     def replay(self):

@@ -248,6 +248,68 @@ def test_stream_overlap_and_graph_replay_are_bit_identical_to_single_stream():
         assert o[5] == outs[0][5] == 5, mode
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_pipelined_iterations_are_bit_identical_to_sequential(dtype):
+    """step_pipelined runs the generator half of iteration i beside the discriminator step of i+1: losses (gen_loss
+    one call later), parameters, Adam state and generator BN statistics must equal the sequential step's bit for
+    bit -- eagerly, with varying inputs, and as a replayed hipGraph."""
+    hw, b, n = (32, 40), 4, 5
+    batches = [synthetic.simnn_inputs(b, hw, seed=70 + i, device=DEV) for i in range(n)]
+
+    def run(kind):
+        gen, disc = _build(9, True, input_hw=hw)
+        gen.to(DEV), disc.to(DEV)
+        tr = SimnnTrainer(gen, disc, compute_dtype=dtype)
+        dls, gls = [], []
+        if kind == "seq":
+            for real, fake, noise in batches:
+                dl, gl = tr.step(real, noise, fake)
+                dls.append(dl.item()); gls.append(gl.item())
+        else:
+            for i, (real, fake, noise) in enumerate(batches):
+                dl, gl = tr.step_pipelined(real, noise, fake)
+                dls.append(dl.item())
+                if i > 0:
+                    gls.append(gl.item())
+            gls.append(tr.flush().item())
+        torch.cuda.synchronize()
+        return dls, gls, [v.detach().clone() for v in tr.d.views], gen.batch_norm3.running_mean.clone(), tr
+
+    seq, pipe = run("seq"), run("pipe")
+    assert seq[0] == pipe[0], (seq[0], pipe[0])
+    assert seq[1] == pipe[1], (seq[1], pipe[1])
+    assert all(torch.equal(u, v) for u, v in zip(seq[2], pipe[2]))
+    assert torch.equal(seq[3], pipe[3])
+    # mixing: a sequential step after pipelined ones flushes the pending half first
+    tr = pipe[4]
+    real, fake, noise = batches[0]
+    tr.step_pipelined(real, noise, fake)
+    tr.step(real, noise, fake)
+    assert tr._pending_fake is None
+
+
+def test_pipelined_graph_replay_matches_sequential_steps():
+    hw, b = (128, 216), 4
+    outs = []
+    for mode in ("seq", "graph"):
+        gen, disc = _build(7, True)
+        gen.to(DEV), disc.to(DEV)
+        tr = SimnnTrainer(gen, disc, compute_dtype="bf16")
+        real, fake, noise = synthetic.simnn_inputs(b, hw, seed=55, device=DEV)
+        if mode == "graph":
+            tr.capture(real, noise, fake, pipelined=True)       # 2 warm-up calls run; the captured call does not
+            for _ in range(3):
+                dl, _ = tr.replay()
+            gl = tr.flush()
+        else:
+            for _ in range(5):
+                dl, gl = tr.step(real, noise, fake)
+        torch.cuda.synchronize()
+        outs.append((dl.item(), gl.item(), disc.fc1.weight.detach().clone(), disc.conv2.weight.detach().clone()))
+    assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1], (outs[0][:2], outs[1][:2])
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+
+
 def test_train_entry_point_runs_and_checkpoints(tmp_path):
     gen, disc, g_losses, d_losses = SIMNN.train(None, batch_size=4, max_steps=7, model_path=str(tmp_path), seed=0,
                                                 log=lambda *_: None)
