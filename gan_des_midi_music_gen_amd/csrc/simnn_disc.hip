@@ -1331,6 +1331,12 @@ inline int conv1_slabs(int64_t total) {
 // they fill the chip (2 resident workgroups per CU x 256 CUs); small batches are cut into row segments (each pays one
 // pseudo step).  A pure function of the shapes: the slab count of the fused variant must be reproducible by _finish.
 struct BdPlan { int n_ctiles, nseg, seg_len, n_items, blocks; };
+// experiments only: grid caps of the persistent kernels from the environment (tools/ sweeps), else the tuned default
+inline int tuned_cap(const char* name, int dflt) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  return v > 0 ? v : dflt;
+}
 inline BdPlan bd_plan(int B, int H1, int W1, bool fuse) {
   BdPlan p;
   const int nrq = (H1 + ROWS - 1) / ROWS;
@@ -1342,7 +1348,8 @@ inline BdPlan bd_plan(int B, int H1, int W1, bool fuse) {
   p.seg_len = (nrq + nseg - 1) / nseg;
   p.nseg = (nrq + p.seg_len - 1) / p.seg_len;
   p.n_items = (int)(strips * p.nseg);
-  const int cap = fuse ? 512 : 768;      // (measured at 2B = 512: 384 -> 132 us, 512 -> 118, 640 -> 121, 768 -> 121)
+  static const int cap_fuse = tuned_cap("GDM_BD_CAP", 512);
+  const int cap = fuse ? cap_fuse : 768;      // (measured at 2B = 512: 384 -> 132 us, 512 -> 118, 640 -> 121, 768 -> 121)
   p.blocks = p.n_items < cap ? p.n_items : cap;
   return p;
 }
@@ -1354,7 +1361,7 @@ inline BdPlan bw_plan(int B, int H1, int W1) {
   const int64_t strips = (int64_t)B * p.n_ctiles;
   // measured at 2B = 512 (1024 strips): 768 workgroups (3 per CU) 73 us, 1024 (4 per CU) 84 us, 512 78 us; finer items
   // (more segments per strip) only add pseudo steps
-  constexpr int cap = 768;
+  static const int cap = tuned_cap("GDM_BW_CAP", 768);
   int nseg = (int)((1024 + strips - 1) / strips);
   const int max_seg = nrq / 2 > 1 ? nrq / 2 : 1;
   nseg = nseg < 1 ? 1 : (nseg > max_seg ? max_seg : nseg);
@@ -1396,7 +1403,8 @@ extern "C" int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* 
               "gdm_simnn_conv1_fwd: batch of %d %dx%d inputs exceeds 2 GiB per tensor", B, H, W);
   const int64_t n_rows = (int64_t)B * H1;                                // a wave walks whole pooled rows
   int64_t blocks = (n_rows + 3) / 4;                                     // 4 waves per workgroup
-  if (blocks > 2048) blocks = 2048;                                      // persistent: 8 workgroups per CU
+  static const int cap1 = tuned_cap("GDM_C1_CAP", 2048);               // persistent: 8 workgroups per CU
+  if (blocks > cap1) blocks = cap1;
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                                        x, w, bias, B, H, W, H1, W1, (int)n_rows, (T*)p1, code1));
   GDM_LAUNCH_OK("gdm_simnn_conv1_fwd");
@@ -1450,7 +1458,8 @@ extern "C" int gdm_simnn_conv2_fwd(const void* p1, const void* pack, const float
   const int H2 = H1 / 2, W2 = W1 / 2;
   const int n_ctiles = (2 * W2 + COLS - 1) / COLS;
   const int n_tiles = B * ((2 * H2 + ROWS - 1) / ROWS) * n_ctiles;
-  dim3 grid((unsigned)(n_tiles < 768 ? n_tiles : 768));        // persistent: 3 workgroups per CU
+  static const int cap = tuned_cap("GDM_C2F_CAP", 768);          // persistent: 3 workgroups per CU
+  dim3 grid((unsigned)(n_tiles < cap ? n_tiles : cap));
   hipStream_t s = (hipStream_t)stream;
   if (dtype == GDM_BF16) {
     const size_t sm = (size_t)(C2<__bf16>::IN_ELEMS + C2<__bf16>::WF_ELEMS) * 2;
