@@ -26,6 +26,8 @@ def main():
     res["fc1 fwd  (B,K)x(K,128)"] = (timeit(lambda: ops.gemm(flat, wf1p.t(), bias_n=bf1, act=ACT_RELU, compute=BF16)), (B * K * 2 + 128 * K * 2) / 1e6)
     res["fc1 dW   (128,B)x(B,K)"] = (timeit(lambda: ops.gemm(dh1.t(), flat, compute=BF16)), (B * K * 2 + 128 * K * 4) / 1e6)
     res["fc1 dX   (B,128)x(128,K)"] = (timeit(lambda: ops.gemm(dh1, wf1p, compute=BF16, out_dtype=BF16)), (B * K * 2 + 128 * K * 2) / 1e6)
+    for sk in (32, 64, 128, 256):
+        res[f"fc1 fwd split_k={sk}"] = (timeit(lambda: ops.gemm(flat, wf1p.t(), bias_n=bf1, act=ACT_RELU, compute=BF16, split_k=sk)), (B * K * 2 + 128 * K * 2) / 1e6)
     dh16 = dh1.to(torch.bfloat16)
     res["fc1 dW, bf16 dh"] = (timeit(lambda: ops.gemm(dh16.t(), flat, compute=BF16)), (B * K * 2 + 128 * K * 4) / 1e6)
     res["fc1 dX, bf16 dh"] = (timeit(lambda: ops.gemm(dh16, wf1p, compute=BF16, out_dtype=BF16)), (B * K * 2 + 128 * K * 2) / 1e6)
