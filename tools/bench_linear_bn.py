@@ -18,12 +18,15 @@ nbt = torch.zeros((), dtype=torch.long, device=dev)
 x0 = torch.randn(B, dims[0], device=dev)
 
 
-def chain(layers):
+xin = [torch.randn(B, d, device=dev) for d in dims[:4]]
+
+
+def chain(layers, act=ACT_SIGMOID, training=True):
     x = x0
     for i in layers:
         b, g, be, rm, rv = ps[i]
-        x = ops.linear_bn_act_fwd(x if x.shape[1] == dims[i] else x0.new_zeros(B, dims[i]), ws[i], b, g, be, rm, rv, nbt,
-                                  act=ACT_SIGMOID)[0]
+        x = ops.linear_bn_act_fwd(x if x.shape[1] == dims[i] else xin[i], ws[i], b, g, be, rm, rv, nbt, act=act,
+                                  training=training)[0]
     return x
 
 
@@ -54,4 +57,7 @@ def graph_time(fn, reps=200):
 print(f"4-layer generator chain        : {graph_time(lambda: chain([0, 1, 2, 3])):7.1f} us  (4 launches)")
 for i in range(4):
     print(f"  layer {i} ({dims[i]:4d} -> {dims[i + 1]:4d}) x 8     : {graph_time(lambda: [chain([i]) for _ in range(8)]) / 8:7.1f} us per launch")
+from gan_des_midi_music_gen_amd.ops import ACT_NONE
+print(f"  layer 1, eval-mode statistics   : {graph_time(lambda: [chain([1], training=False) for _ in range(8)]) / 8:7.1f} us per launch")
+print(f"  layer 1, no activation          : {graph_time(lambda: [chain([1], act=ACT_NONE) for _ in range(8)]) / 8:7.1f} us per launch")
 print(f"8 dependent 64-element adds    : {graph_time(lambda: fills(8)) / 8:7.1f} us per launch")
