@@ -12,6 +12,7 @@ namespace {
 
 constexpr int LB_M = 256, LB_N = 32, LB_KT = 32, LB_LD = LB_KT + 8;
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ gamma,
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restr
 
   // Staging: 16-byte loads (K % 4 == 0 and 16-byte aligned rows, else a scalar path), all loads of a k-tile in flight
   // together and one k-tile ahead of the MFMAs (register prefetch): these layers are latency-bound, not bandwidth-bound.
-  const bool vec = (K % 4 == 0) && ((((uintptr_t)x | (uintptr_t)w) & 15) == 0);
+  // VEC (chosen on the host): K % 4 == 0 and 16-byte aligned operands -> every chunk is inside or outside the row as a whole
   f32x4 ra[8], rb;
   auto load_tile = [&](int k0) {
 #pragma unroll
@@ -48,10 +49,12 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restr
       ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (m < M) {
         const float* p = x + (int64_t)m * K + k;
-        if (vec && k + 3 < K) ra[i] = *(const f32x4*)p;
-        else
+        if constexpr (VEC) {
+          if (k < K) ra[i] = *(const f32x4*)p;
+        } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) ra[i][e] = (k + e < K) ? p[e] : 0.f;
+        }
       }
     }
     {
@@ -59,10 +62,12 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restr
       rb = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (n0 + n < N) {
         const float* p = w + (int64_t)(n0 + n) * K + k;
-        if (vec && k + 3 < K) rb = *(const f32x4*)p;
-        else
+        if constexpr (VEC) {
+          if (k < K) rb = *(const f32x4*)p;
+        } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e) rb[e] = (k + e < K) ? p[e] : 0.f;
+        }
       }
     }
   };
@@ -170,6 +175,20 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restr
     const int n = n0 + 16 * j + lr;
     if (n >= N) continue;
     const float alpha = invstd[j] * gamma[n], bt = beta[n];
+    if (M == LB_M && act == GDM_ACT_SIGMOID && !y_out) {
+      // the generators' case (full batch, sigmoid, forward only): no per-element branch, so the 16 stores of a column
+      // issue back to back (with a branch around every store the compiler waited for each one: ~12 us per launch)
+      float o[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[i][r] = apply_act((acc[i][j][r] - mean[j]) * alpha + bt, GDM_ACT_SIGMOID, 0.f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(int64_t)(64 * wv + 16 * i + 4 * lg + r) * N + n] = o[i][r];
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -197,9 +216,15 @@ extern "C" int gdm_linear_bn_act_fwd(const float* x, const float* w, const float
   GDM_REQUIRE(M >= 1 && M <= LB_M && N >= 1 && K >= 1, "gdm_linear_bn_act_fwd: M=%d outside 1..%d (or bad N/K)", M, LB_M);
   GDM_REQUIRE(!training || M > 1, "gdm_linear_bn_act_fwd: training-mode batch norm needs more than 1 row");
   GDM_REQUIRE(training || (running_mean && running_var), "gdm_linear_bn_act_fwd: eval mode needs running statistics");
-  hipLaunchKernelGGL(linear_bn_act_kernel, dim3((N + LB_N - 1) / LB_N), dim3(256), 0, (hipStream_t)stream, x, w, bias,
-                     gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, act, training, M, N, K,
-                     y_out, out, save_mean, save_invstd);
+  const bool vec = (K % 4 == 0) && ((((uintptr_t)x | (uintptr_t)w) & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL(linear_bn_act_kernel<true>, dim3((N + LB_N - 1) / LB_N), dim3(256), 0, (hipStream_t)stream, x, w,
+                       bias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, act, training, M,
+                       N, K, y_out, out, save_mean, save_invstd);
+  else
+    hipLaunchKernelGGL(linear_bn_act_kernel<false>, dim3((N + LB_N - 1) / LB_N), dim3(256), 0, (hipStream_t)stream, x, w,
+                       bias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, act, training,
+                       M, N, K, y_out, out, save_mean, save_invstd);
   GDM_LAUNCH_OK("gdm_linear_bn_act_fwd");
   return GDM_OK;
 }
