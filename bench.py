@@ -18,6 +18,8 @@ CPU oracle (oracle/, this repo's restatement of the reference loop) is timed on 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -73,15 +75,52 @@ def parse():
     return ap.parse_args()
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a torchrun environment: start N ranks ourselves (one process per GPU) as a
+    CHILD `python -m torch.distributed.run ... bench.py <same arguments>`, relay its output (rank 0 prints the JSON
+    line) and return its exit code.  This process never touches the GPU (no exec, no HIP call before or after)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on these hosts
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def setup_dist(n):
     from gan_des_midi_music_gen_amd import dp
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if n > 1 or world > 1:
         if world != n:
-            raise SystemExit(f"--gpus {n} needs torchrun with {n} ranks (WORLD_SIZE={world})")
+            raise SystemExit(f"--gpus {n} but the torchrun environment has WORLD_SIZE={world}")
         return dp.init_from_env("nccl")
     torch.cuda.set_device(0)
     return 0, 1, 0
+
+
+def rendezvous_only(args):
+    """GDM_BENCH_RENDEZVOUS_ONLY=1 (CPU rehearsal of the launcher, tests/test_bench_launcher.py): every rank joins the
+    process group (gloo), proves the collective works and rank 0 prints a JSON line -- no GPU is touched."""
+    import torch.distributed as dist
+    from gan_des_midi_music_gen_amd import dp
+    os.environ.setdefault("GDM_DIST_BACKEND", "gloo")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ["GDM_DIST_BACKEND"])
+    rank = dist.get_rank() if world > 1 else 0
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dp.allreduce_bucket_(t, 1)
+    if rank == 0:
+        print(json.dumps({"rendezvous_only": True, "n_gpus": world, "requested": args.gpus,
+                          "rank_sum": t.item()}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def build_simnn(args, rank, dev):
@@ -190,12 +229,19 @@ def cpu_baseline(args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))        # before anything touches the GPU in this process
+    if os.environ.get("GDM_BENCH_RENDEZVOUS_ONLY") == "1":
+        return rendezvous_only(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
     rank, world, local = setup_dist(args.gpus)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    from gan_des_midi_music_gen_amd import ops
+    from gan_des_midi_music_gen_amd import _lib, ops
+    if _lib.load().gdm_build_flavor() != 0:
+        raise SystemExit("libgdm_hip.so was built with experiment switches (GDM_HIPCC_FLAGS): rebuild with the shipped "
+                         "flags (`python -m gan_des_midi_music_gen_amd.build`) before benchmarking")
 
     tr, step, eager_step = (build_simnn if args.workload == "simnn" else build_mmgan)(args, rank, dev)
 
@@ -218,7 +264,7 @@ def main():
         elapsed = t.item()
     if hasattr(tr, "flush"):
         tr.flush()       # pipelined schedule: the last iteration's generator half (its twin ran before the timed region)
-    losses = (tr.disc_loss_value(), tr.gen_loss_value())
+    losses = (tr.disc_loss_value(), tr.gen_loss_global())      # global-batch means (gen_loss: one tiny collective)
 
     roofline = None
     if not args.no_roofline:

@@ -6,7 +6,7 @@ Same public names, constructor signatures, state_dict keys and training-loop sem
     weights_init(m)                                               SIMNN.py:49-59
     Generator(no_of_channels=1, noise_dim=100, gen_dim=32)        SIMNN.py:62-112
     Discriminator(no_of_channels=1, disc_dim=32)                  SIMNN.py:115-142
-    SimNN(n)                                                      SIMNN.py:145-198 (name + signature only, see class)
+    SimNN(n)                                                      SIMNN.py:145-170
     generate_song(model_folder)                                   SIMNN.py:201-216
     train(...)  /  python -m gan_des_midi_music_gen_amd.SIMNN     SIMNN.py:234-348 (the __main__ loop)
 
@@ -108,11 +108,14 @@ class Discriminator(nn.Module):
 
 
 class SimNN(nn.Module):
-    """Experimental CNN of the reference (SIMNN.py:145-198); never reached by its training loop.
+    """Experimental CNN of the reference (SIMNN.py:145-198): spectrogram (B,1,H,W) -> (n x n matrix, 4 length-n
+    vectors).  Never reached by the reference's training loop; kept complete for the API.
 
-    The reference re-creates ``fc1`` with fresh random weights on every forward (SIMNN.py:161), so it has no
-    reproducible numeric behaviour to match; only the name, constructor and parameter containers are kept
-    ("next").  ``forward`` raises.
+    As upstream, ``forward`` RE-CREATES ``fc1`` with fresh default-initialised weights on every call, sized to the
+    flattened feature map (SIMNN.py:161: ``self.fc1 = nn.Linear(x.size(1), 512).to(x.device)`` -- drawn on the CPU
+    generator, then moved), so results are reproducible only under a fixed ``torch.manual_seed`` right before the call
+    (that is how tests/golden/simnn_net.npz pins it).  Convolutions run as im2col + MFMA GEMM with fused bias/ReLU,
+    pooling and the dense layers on the generic kernels behind include/gdm.h.
     """
 
     def __init__(self, n):
@@ -120,12 +123,23 @@ class SimNN(nn.Module):
         self.n = n
         self.conv1 = nn.Conv2d(1, 32, kernel_size=3, stride=1, padding=1)
         self.conv2 = nn.Conv2d(32, 64, kernel_size=3, stride=1, padding=1)
-        self.fc1 = nn.Linear(64 * 32 * 32, 512)
+        self.fc1 = nn.Linear(64 * 32 * 32, 512)  # replaced in forward, like upstream
         self.fc2 = nn.Linear(512, self.n * self.n + 4 * self.n)
+        self.compute_dtype = None
 
     def forward(self, x):
-        raise NotImplementedError("SimNN is outside the MI355X hot-path scope (dead code in the reference: "
-                                  "GAN_DES/SIMNN.py:145-198 is never called by the training loop)")
+        dt = Fn.get_compute_dtype() if self.compute_dtype is None else Fn._NAMES[self.compute_dtype]
+        feat = 64 * (x.size(2) // 4) * (x.size(3) // 4)
+        self.fc1 = nn.Linear(feat, 512).to(x.device)                  # SIMNN.py:161
+        output = Fn.SimnnNetFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                     self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, dt)
+        n = self.n
+        matrix = output[:, :n * n].view(-1, n, n)
+        array1 = output[:, n * n:n * n + n]
+        array2 = output[:, n * n + n:n * n + 2 * n]
+        array3 = output[:, n * n + 2 * n:n * n + 3 * n]
+        array4 = output[:, n * n + 3 * n:]
+        return matrix, array1, array2, array3, array4
 
     @staticmethod
     def create_model(n):

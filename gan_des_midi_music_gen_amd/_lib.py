@@ -17,6 +17,7 @@ SIGNATURES = {
     "gdm_last_error": (_c.c_char_p, []),
     "gdm_version": (_I, []),
     "gdm_arch": (_c.c_char_p, []),
+    "gdm_build_flavor": (_I, []),
     "gdm_gemm": (_I, [_P, _I, _L, _L, _P, _I, _L, _L, _P, _I, _L, _L, _I, _I, _I, _P, _P, _I, _F, _I, _I, _P, _Z, _P]),
     "gdm_bce_with_logits": (_I, [_P, _F, _I, _F, _P, _P, _I, _I, _P]),
     "gdm_adam_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P]),
@@ -43,6 +44,7 @@ SIGNATURES = {
     "gdm_simnn_conv2_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P, _Z, _P]),
     "gdm_simnn_conv1_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I]),
     "gdm_simnn_conv1_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _P, _Z, _P]),
+    "gdm_simnn_conv1_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P]),
     "gdm_simnn_head_workspace_bytes": (_Z, [_I]),
     "gdm_simnn_head": (_I, [_P, _P, _P, _I, _I, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "gdm_linear_bn_act_max_rows": (_I, []),
@@ -55,6 +57,10 @@ SIGNATURES = {
     "gdm_im2col": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "gdm_col2im": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "gdm_permute_pc": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
+    "gdm_des_scan": (_I, [_P, _L, _I, _I, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "gdm_des_routing": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P]),
+    "gdm_maxpool2_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "gdm_maxpool2_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
 }
 
 _lock = threading.Lock()

@@ -19,7 +19,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
          # no NaN handling in the arithmetic: without it every MFMA result that reaches an fmaxf is first
          # canonicalised (v_max_f32 x, x, x) -- 16 extra VALU per 16 pooled pixels in the issue-bound conv epilogues
          "-fno-honor-nans"]
-FLAGS += os.environ.get("GDM_HIPCC_FLAGS", "").split()     # experiment switches (-D...), empty for the shipped build
+EXPERIMENT = os.environ.get("GDM_HIPCC_FLAGS", "").split()     # experiment switches (-D...), empty for the shipped build
+if EXPERIMENT:
+    # an instrumented / variant build says so: gdm_build_flavor() returns 1 and bench.py refuses to measure it
+    FLAGS += EXPERIMENT + ["-DGDM_EXPERIMENT_BUILD=1"]
+STAMP = os.path.join(OBJ, "flags.txt")
 
 
 def _hipcc():
@@ -36,9 +40,25 @@ def _newer(src, dst, extra=()):
     return any(os.path.getmtime(p) > t for p in (src, *extra))
 
 
+def _flags_stamp(hipcc):
+    """What the objects depend on besides their sources: the compile flags and the compiler."""
+    try:
+        ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        ver = "?"
+    return " ".join(FLAGS) + "\n" + ver + "\n"
+
+
 def build(force=False, verbose=False):
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
+    stamp = _flags_stamp(hipcc)
+    try:
+        same = open(STAMP).read() == stamp
+    except OSError:
+        same = False
+    if not same:
+        force = True       # objects from another flag set (e.g. -DGDM_STAMPS experiments) must not be linked in
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG, "..", "include", "*.h"))
     jobs = []
@@ -59,6 +79,8 @@ def build(force=False, verbose=False):
                 sys.stderr.write(f"[build] {os.path.basename(s)} rc={rc}\n{out}\n")
             if rc != 0:
                 raise RuntimeError(f"hipcc failed on {s}")
+    with open(STAMP, "w") as f:
+        f.write(stamp)
     objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in srcs]
     if force or jobs or not os.path.exists(LIB):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]

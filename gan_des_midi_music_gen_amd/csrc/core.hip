@@ -13,3 +13,8 @@ void gdm_set_error(const char* fmt, ...) {
 extern "C" const char* gdm_last_error(void) { return g_err; }
 extern "C" int gdm_version(void) { return 1; }
 extern "C" const char* gdm_arch(void) { return "gfx950"; }
+#ifdef GDM_EXPERIMENT_BUILD
+extern "C" int gdm_build_flavor(void) { return 1; }
+#else
+extern "C" int gdm_build_flavor(void) { return 0; }
+#endif

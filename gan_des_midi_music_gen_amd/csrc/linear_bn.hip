@@ -3,8 +3,11 @@
 //
 // A 256-thread workgroup owns ALL M rows of a 32-column strip of the output, so the batch statistics of its columns
 // never leave the workgroup: y = x W^T + b is accumulated on v_mfma_f32_16x16x32_bf16 (wave w: rows [64w, 64w+64),
-// 4 x 2 accumulator tiles), the column mean is reduced registers -> lanes -> waves (LDS), the variance is a second pass
-// over the SAME registers (exact two-pass, no E[x^2]-E[x]^2 cancellation), running statistics are updated by the
+// 4 x 2 accumulator tiles) with SPLIT operands -- x = xh + xl, W = wh + wl in bf16, y += xh wh + xh wl + xl wh (the
+// dropped xl wl term is 2^-16 relative) -- because these layers are latency-bound (<= 13 MFLOP per launch), so three
+// MFMAs per tile cost nothing, while plain bf16 operands put 5e-2 of error on the generated DES parameters (beat times
+// up to ~27 s enter un-normalised, network_tests.py:119): the generated matrices are the product of this path.  The column mean is reduced
+// registers -> lanes -> waves (LDS), the variance is a second pass over the SAME registers (exact two-pass, no E[x^2]-E[x]^2 cancellation), running statistics are updated by the
 // owning workgroup, and the normalised + activated strip is stored.  Replaces GEMM + 3 batch-norm launches per layer.
 #include "gdm_common.h"
 
@@ -24,8 +27,8 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restr
                                                             float* __restrict__ y_out, float* __restrict__ out,
                                                             float* __restrict__ save_mean,
                                                             float* __restrict__ save_invstd) {
-  __shared__ __attribute__((aligned(16))) __bf16 As[LB_M * LB_LD];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[LB_N * LB_LD];
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][LB_M * LB_LD];     // [hi | lo]
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][LB_N * LB_LD];
   __shared__ float colred[4][LB_N];
   __shared__ float colstat[2][LB_N];
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
@@ -77,27 +80,36 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int idx = t + 256 * i;
-      bf16x4 h;
+      bf16x4 h, lo;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) h[e] = (__bf16)ra[i][e];
-      *(bf16x4*)&As[(idx >> 3) * LB_LD + (idx & 7) * 4] = h;
+      for (int e = 0; e < 4; ++e) { h[e] = (__bf16)ra[i][e]; lo[e] = (__bf16)(ra[i][e] - (float)h[e]); }
+      *(bf16x4*)&As[0][(idx >> 3) * LB_LD + (idx & 7) * 4] = h;
+      *(bf16x4*)&As[1][(idx >> 3) * LB_LD + (idx & 7) * 4] = lo;
     }
     {
-      bf16x4 h;
+      bf16x4 h, lo;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) h[e] = (__bf16)rb[e];
-      *(bf16x4*)&Bs[(t >> 3) * LB_LD + (t & 7) * 4] = h;
+      for (int e = 0; e < 4; ++e) { h[e] = (__bf16)rb[e]; lo[e] = (__bf16)(rb[e] - (float)h[e]); }
+      *(bf16x4*)&Bs[0][(t >> 3) * LB_LD + (t & 7) * 4] = h;
+      *(bf16x4*)&Bs[1][(t >> 3) * LB_LD + (t & 7) * 4] = lo;
     }
     __syncthreads();
     if (k0 + LB_KT < K) load_tile(k0 + LB_KT);
-    bf16x8 b[2];
+    bf16x8 b[2][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8*)&Bs[(16 * j + lr) * LB_LD + 8 * lg];
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) b[h][j] = *(const bf16x8*)&Bs[h][(16 * j + lr) * LB_LD + 8 * lg];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const bf16x8 a = *(const bf16x8*)&As[(64 * wv + 16 * i + lr) * LB_LD + 8 * lg];
+      const bf16x8 ah = *(const bf16x8*)&As[0][(64 * wv + 16 * i + lr) * LB_LD + 8 * lg];
+      const bf16x8 al = *(const bf16x8*)&As[1][(64 * wv + 16 * i + lr) * LB_LD + 8 * lg];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a, b[j], acc[i][j]);
+      for (int j = 0; j < 2; ++j) {      // small terms first
+        acc[i][j] = mfma16(al, b[0][j], acc[i][j]);
+        acc[i][j] = mfma16(ah, b[1][j], acc[i][j]);
+        acc[i][j] = mfma16(ah, b[0][j], acc[i][j]);
+      }
     }
   }
   // C layout: col = n (16j + lr), row = m (64wv + 16i + 4lg + r).  Add the Linear bias.

@@ -84,6 +84,48 @@ __global__ __launch_bounds__(256) void permute_pc_kernel(const void* __restrict_
   }
 }
 
+// 2x2 / stride-2 max-pool on channels-last activations (F.max_pool2d(x, 2, 2), GAN_DES/SIMNN.py:156,158: the SimNN
+// branch; model 1's discriminator pools inside its conv kernels).  idx = window position 0..3 of the FIRST maximum in
+// scan order (aten::max_pool2d_with_indices); the backward routes the gradient there, zeros elsewhere (also into the
+// odd last row/column the floor pooling drops).
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const void* __restrict__ src, int sd, int B, int H, int W,
+                                                           int C, void* __restrict__ dst, uint8_t* __restrict__ idx) {
+  const int OH = H / 2, OW = W / 2;
+  const int64_t total = (int64_t)B * OH * OW * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int ow = (int)((i / C) % OW), oh = (int)((i / ((int64_t)C * OW)) % OH), b = (int)(i / ((int64_t)C * OW * OH));
+    const int64_t base = (((int64_t)b * H + 2 * oh) * W + 2 * ow) * C + c;
+    const float v0 = load_as_f32(src, sd, base), v1 = load_as_f32(src, sd, base + C);
+    const float v2 = load_as_f32(src, sd, base + (int64_t)W * C), v3 = load_as_f32(src, sd, base + (int64_t)W * C + C);
+    float m = v0;
+    int pos = 0;
+    if (v1 > m) { m = v1; pos = 1; }
+    if (v2 > m) { m = v2; pos = 2; }
+    if (v3 > m) { m = v3; pos = 3; }
+    store_from_f32(dst, sd, i, m);
+    if (idx) idx[i] = (uint8_t)pos;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const void* __restrict__ dout, int dd,
+                                                           const uint8_t* __restrict__ idx, int B, int H, int W, int C,
+                                                           void* __restrict__ dx) {
+  const int OH = H / 2, OW = W / 2;
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int w = (int)((i / C) % W), h = (int)((i / ((int64_t)C * W)) % H), b = (int)(i / ((int64_t)C * W * H));
+    float g = 0.f;
+    const int oh = h >> 1, ow = w >> 1;
+    if (oh < OH && ow < OW) {
+      const int64_t o = (((int64_t)b * OH + oh) * OW + ow) * C + c;
+      if (idx[o] == (uint8_t)((h & 1) * 2 + (w & 1))) g = load_as_f32(dout, dd, o);
+    }
+    store_from_f32(dx, dd, i, g);
+  }
+}
+
 inline unsigned grid_for(int64_t total) {
   int64_t b = (total + 255) / 256;
   return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -157,5 +199,26 @@ extern "C" int gdm_permute_pc(const void* src, int src_dtype, int B, int P, int 
                        src_dtype, P, C, dst, dst_dtype);
   }
   GDM_LAUNCH_OK("gdm_permute_pc");
+  return GDM_OK;
+}
+
+extern "C" int gdm_maxpool2_fwd(const void* src, int dtype, int B, int H, int W, int C, void* dst, uint8_t* idx_or_null,
+                                void* stream) {
+  GDM_REQUIRE(src && dst && B > 0 && H >= 2 && W >= 2 && C > 0 && gdm_dtype_ok(dtype), "gdm_maxpool2_fwd: bad arguments");
+  const int64_t total = (int64_t)B * (H / 2) * (W / 2) * C;
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, dtype, B, H, W,
+                     C, dst, idx_or_null);
+  GDM_LAUNCH_OK("gdm_maxpool2_fwd");
+  return GDM_OK;
+}
+
+extern "C" int gdm_maxpool2_bwd(const void* dout, int dtype, const uint8_t* idx, int B, int H, int W, int C, void* dx,
+                                void* stream) {
+  GDM_REQUIRE(dout && idx && dx && B > 0 && H >= 2 && W >= 2 && C > 0 && gdm_dtype_ok(dtype),
+              "gdm_maxpool2_bwd: bad arguments");
+  const int64_t total = (int64_t)B * H * W * C;
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout, dtype, idx, B,
+                     H, W, C, dx);
+  GDM_LAUNCH_OK("gdm_maxpool2_bwd");
   return GDM_OK;
 }

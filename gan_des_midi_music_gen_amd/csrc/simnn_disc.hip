@@ -291,6 +291,48 @@ __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restri
 }
 
 // =====================================================================================================================
+// conv1 backward (data): dx[i][j] = sum_{c,kh,kw} w[c][kh][kw] * dy[c][i+1-kh][j+1-kw], where dy is the sparse
+// full-resolution gradient of the (H+1)x(W+1) conv output: dy[c][oh][ow] = dp1[oh/2][ow/2][c] if channel c of that
+// pooled pixel is live and its argmax position is (oh&1, ow&1), else 0 (conv rows/columns beyond 2*H1 / 2*W1 were
+// dropped by the floor pooling).  Not on the reference's training path (the discriminator's inputs are data or detached
+// bridge outputs, SIMNN.py:283,299-306): this completes the module's autograd (aten::convolution_backward input grad,
+// SIMNN.py:136).  One thread per input pixel; the <= 4 pooled pixels it touches are read straight from HBM/L2.
+// =====================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_bwd_data_kernel(const T* __restrict__ dp1,
+                                                             const uint64_t* __restrict__ code1,
+                                                             const float* __restrict__ w, int B, int H, int W, int H1,
+                                                             int W1, float* __restrict__ dx) {
+  __shared__ float ws[64];
+  if (threadIdx.x < 64) ws[threadIdx.x] = w[threadIdx.x];
+  __syncthreads();
+  const int64_t total = (int64_t)B * H * W;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int j = (int)(idx % W), i = (int)((idx / W) % H), b = (int)(idx / ((int64_t)W * H));
+    float acc = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw) {
+        const int oh = i + 1 - kh, ow = j + 1 - kw;          // >= 0 always
+        const int ph = oh >> 1, pw = ow >> 1;
+        if (ph >= H1 || pw >= W1) continue;
+        const int64_t pix = ((int64_t)b * H1 + ph) * W1 + pw;
+        const uint64_t code = code1[pix];
+        const uint32_t pos_here = (uint32_t)((oh & 1) * 2 + (ow & 1));
+        const T* g16 = dp1 + pix * 16;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const uint32_t field = (uint32_t)(code >> (16 * (c >> 2))) & 0xffffu;   // code1 format: see conv1_fwd_kernel
+          const bool hit = ((field >> (8 + (c & 3))) & 1u) && ((field >> (2 * (c & 3))) & 3u) == pos_here;
+          acc += hit ? ws[c * 4 + kh * 2 + kw] * to_f32(g16[c]) : 0.f;
+        }
+      }
+    dx[idx] = acc;
+  }
+}
+
+// =====================================================================================================================
 // Fixed-order sum of `nslabs` slabs of `width` floats (deterministic replacement for float atomics), with the
 // gradient's final placement fused into the last level.
 // A 1024-thread workgroup owns 64 consecutive elements of one slab group; wave w adds slabs w, w+16, ... of its group
@@ -1433,6 +1475,20 @@ extern "C" int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1
   float* scratch = (float*)workspace + (size_t)nslabs * 80;
   launch_slab_sum<1>((const float*)workspace, nslabs, 80, scratch, dw, db, accumulate, s);
   GDM_LAUNCH_OK("gdm_simnn_conv1_bwd_weight");
+  return GDM_OK;
+}
+
+extern "C" int gdm_simnn_conv1_bwd_data(const void* dp1, const uint64_t* code1, const float* w, int B, int H, int W,
+                                        float* dx, int dtype, void* stream) {
+  GDM_REQUIRE(dp1 && code1 && w && dx, "gdm_simnn_conv1_bwd_data: null pointer");
+  GDM_REQUIRE(B > 0 && H >= 1 && W >= 1 && gdm_dtype_ok(dtype), "gdm_simnn_conv1_bwd_data: bad arguments");
+  const int H1 = (H + 1) / 2, W1 = (W + 1) / 2;
+  const int64_t total = (int64_t)B * H * W;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_bwd_data_kernel<T>, dim3((unsigned)blocks), dim3(256), 0,
+                                       (hipStream_t)stream, (const T*)dp1, code1, w, B, H, W, H1, W1, dx));
+  GDM_LAUNCH_OK("gdm_simnn_conv1_bwd_data");
   return GDM_OK;
 }
 

@@ -84,11 +84,12 @@ def simnn_disc_forward(x, w1, b1, pack, b2, wf1p, bf1, wf2, bf2, dt, trunk_out=N
     return p, saved + (p,)
 
 
-def simnn_disc_backward_from_dh1(saved, dh1, pack, wf1p, dt, out=None, x_pair=None):
+def simnn_disc_backward_from_dh1(saved, dh1, pack, wf1p, dt, out=None, x_pair=None, w1_for_dx=None):
     """dh1 (B,128) fp32 = gradient w.r.t. fc1's pre-activation (already through the ReLU).
 
-    Returns (dw1, db1, dw2, db2, dwf1); ``out`` = the 8 gradient tensors in parameter order (only the first five
-    are written).  x_pair = (x0, x1) when the batch is the concatenation of two input tensors."""
+    Returns (dw1, db1, dw2, db2, dwf1, dx); ``out`` = the 8 gradient tensors in parameter order (only the first five
+    are written).  x_pair = (x0, x1) when the batch is the concatenation of two input tensors.  dx (B,H,W) = gradient
+    w.r.t. the input, computed only when ``w1_for_dx`` (conv1.weight) is given (else None)."""
     x, p1, code1, flat, code2 = saved[:5]
     b = p1.shape[0]
     o = out if out is not None else [None] * 8
@@ -100,13 +101,18 @@ def simnn_disc_backward_from_dh1(saved, dh1, pack, wf1p, dt, out=None, x_pair=No
     dp2 = dflat.view(b, h1s // 2, w1s // 2, 32)
     dw2, db2 = ops.simnn_conv2_bwd_weight(dp2, code2, p1, out=None if out is None else (o[2], o[3]))
     x0, x1 = x_pair if x_pair is not None else (x, None)
-    dw1, db1, _ = ops.simnn_conv2_bwd_fused(dp2, code2, pack, code1, x0, x1, out=None if out is None else (o[0], o[1]))
-    return dw1, db1, dw2, db2, dwf1
+    dw1, db1, dp1 = ops.simnn_conv2_bwd_fused(dp2, code2, pack, code1, x0, x1,
+                                              out=None if out is None else (o[0], o[1]), want_dp1=w1_for_dx is not None)
+    dx = None
+    if w1_for_dx is not None:
+        dx = ops.simnn_conv1_bwd_data(dp1, code1, w1_for_dx.contiguous(), x0.shape[1], x0.shape[2])
+    return dw1, db1, dw2, db2, dwf1, dx
 
 
-def simnn_disc_backward(saved, dz, pack, wf1p, wf2, dt, out=None, x_pair=None):
+def simnn_disc_backward(saved, dz, pack, wf1p, wf2, dt, out=None, x_pair=None, w1_for_dx=None):
     """dz (B,1) fp32 = d loss / d (pre-sigmoid logit).  Returns grads in parameter order
-    (w1,b1,w2,b2,wf1,bf1,wf2,bf2); ``out`` = 8 preallocated gradient tensors to fill instead."""
+    (w1,b1,w2,b2,wf1,bf1,wf2,bf2) + the input gradient (None unless ``w1_for_dx`` = conv1.weight is given);
+    ``out`` = 8 preallocated gradient tensors to fill instead."""
     h1 = saved[5]
     b = h1.shape[0]
     o = out if out is not None else [None] * 8
@@ -115,8 +121,8 @@ def simnn_disc_backward(saved, dz, pack, wf1p, wf2, dt, out=None, x_pair=None):
     dbf2 = ops.colsum(dz, out=o[7])
     dh1 = ops.act_bwd(ops.gemm(dz, wf2, compute=dt), h1, act=ACT_RELU)        # (B,128)
     dbf1 = ops.colsum(dh1, out=o[5])
-    dw1, db1, dw2, db2, dwf1 = simnn_disc_backward_from_dh1(saved, dh1, pack, wf1p, dt, out, x_pair)
-    return dw1, db1, dw2, db2, dwf1, dbf1, dwf2, dbf2
+    dw1, db1, dw2, db2, dwf1, dx = simnn_disc_backward_from_dh1(saved, dh1, pack, wf1p, dt, out, x_pair, w1_for_dx)
+    return dw1, db1, dw2, db2, dwf1, dbf1, dwf2, dbf2, dx
 
 
 class SimnnDiscFn(torch.autograd.Function):
@@ -126,21 +132,24 @@ class SimnnDiscFn(torch.autograd.Function):
         p, saved = simnn_disc_forward(x, w1.detach(), b1.detach(), pack, b2.detach(), wf1p, bf1.detach(),
                                       wf2.detach(), bf2.detach(), dt)
         ctx.saved = saved
-        ctx.weights = (pack, wf1p, wf2.detach())
+        ctx.weights = (pack, wf1p, wf2.detach(), w1.detach())
         ctx.dt = dt
         ctx.x_needs_grad = x.requires_grad
+        ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
         return p
 
     @staticmethod
     def backward(ctx, dp):
-        if ctx.x_needs_grad:
-            raise NotImplementedError("gradient w.r.t. the discriminator's spectrogram input is not on the reference's "
-                                      "path (its inputs are data or detached bridge outputs, SIMNN.py:283,299-306)")
         p = ctx.saved[-1]
         dz = ops.act_bwd(dp.contiguous().float(), p, act=ACT_SIGMOID)
-        pack, wf1p, wf2 = ctx.weights
-        grads = simnn_disc_backward(ctx.saved, dz, pack, wf1p, wf2, ctx.dt)
-        return (None, *grads, None)
+        pack, wf1p, wf2, w1 = ctx.weights
+        # the reference's own loops never ask for the input gradient (data / detached bridge outputs, SIMNN.py:283,
+        # 299-306), but the module is an ordinary autograd citizen: dx on request
+        *grads, dx = simnn_disc_backward(ctx.saved, dz, pack, wf1p, wf2, ctx.dt,
+                                         w1_for_dx=w1 if ctx.x_needs_grad else None)
+        if dx is not None:
+            dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
+        return (dx, *grads, None)
 
 
 # ======================================================================================================================
@@ -364,8 +373,9 @@ def dcnn_forward(image, w1, b1, w2, b2, wf, bf, dt):
     return logits, (cols1, a1, cols2, a2, flat, (b, oh1, ow1, oh2, ow2, co1, co2))
 
 
-def dcnn_backward(saved, dlogits, w2, wf, dt):
-    """dlogits (B,1) fp32.  Returns (dw1, db1, dw2, db2, dwf, dbf)."""
+def dcnn_backward(saved, dlogits, w2, wf, dt, w1_for_dx=None, in_hw=None):
+    """dlogits (B,1) fp32.  Returns (dw1, db1, dw2, db2, dwf, dbf, dx): dx (B,C,H,T) fp32 = gradient w.r.t. the
+    piano-roll input when ``w1_for_dx`` (conv1.weight) and ``in_hw`` = (C, H, T) are given, else None."""
     cols1, a1, cols2, a2, flat, (b, oh1, ow1, oh2, ow2, co1, co2) = saved
     dl = _f32c(dlogits).view(b, 1)
     dwf = ops.gemm(dl.t(), flat, compute=dt)
@@ -381,7 +391,13 @@ def dcnn_backward(saved, dlogits, w2, wf, dt):
     dy1 = ops.act_bwd(da1, a1, act=ACT_LEAKY, slope=0.2)
     dw1 = ops.gemm(dy1.t(), cols1, compute=dt).view(co1, -1, 4, 4)
     db1 = ops.colsum(dy1)
-    return dw1, db1, dw2, db2, dwf, dbf
+    dx = None
+    if w1_for_dx is not None:
+        c, h, t = in_hw
+        dcols1 = ops.gemm(dy1, w1_for_dx.reshape(co1, -1), compute=dt, out_dtype=F32)      # (B*oh1*ow1, C*16)
+        dx = ops.col2im(dcols1, b=b, h=h, w=t, c=c, kh=4, kw=4, stride=2, pad=1, oh=oh1, ow=ow1, out_dtype=F32,
+                        planar=True)
+    return dw1, db1, dw2, db2, dwf, dbf, dx
 
 
 class DcnnFn(torch.autograd.Function):
@@ -390,19 +406,22 @@ class DcnnFn(torch.autograd.Function):
         logits, saved = dcnn_forward(image, w1.detach(), b1.detach(), w2.detach(), b2.detach(), wf.detach(),
                                      bf.detach(), dt)
         ctx.saved, ctx.dt = saved, dt
-        ctx.weights = (w2.detach(), wf.detach())
+        ctx.weights = (w2.detach(), wf.detach(), w1.detach())
         ctx.x_needs_grad = image.requires_grad
+        ctx.x_shape, ctx.x_dtype = image.shape, image.dtype
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
-        if ctx.x_needs_grad:
-            raise NotImplementedError("gradient w.r.t. the piano-roll input is not on the reference's path "
-                                      "(bridge outputs carry no graph, network_tests.py:189-193)")
-        w2, wf = ctx.weights
-        grads = dcnn_backward(ctx.saved, dlogits, w2, wf, ctx.dt)
+        w2, wf, w1 = ctx.weights
+        # the reference's loop never asks for the input gradient (bridge outputs carry no graph, network_tests.py:189-193);
+        # computed on request so that the module is an ordinary autograd citizen
+        *grads, dx = dcnn_backward(ctx.saved, dlogits, w2, wf, ctx.dt, w1_for_dx=w1 if ctx.x_needs_grad else None,
+                                   in_hw=tuple(ctx.x_shape[1:]))
         dw1 = grads[0].view(ctx.saved[-1][5], -1, 4, 4)
-        return (None, dw1, *grads[1:], None)
+        if dx is not None:
+            dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
+        return (dx, dw1, *grads[1:], None)
 
 
 # ======================================================================================================================
@@ -443,3 +462,71 @@ class MlpLeakyFn(torch.autograd.Function):
     def backward(ctx, dout):
         dx, grads = mlp_leaky_backward(ctx.saved, dout, ctx.layers, ctx.dt, ctx.need_dx)
         return (dx, *[g for layer in grads for g in layer], None)
+
+
+# ======================================================================================================================
+# SimNN (GAN_DES/SIMNN.py:145-170): Conv(1->32,k3,p1) ReLU pool, Conv(32->64,k3,p1) ReLU pool, flatten (channel-major),
+# Linear(.,512) ReLU, Linear(512, n*n+4n).  Not on the training path: generic kernels.
+# ======================================================================================================================
+def simnn_net_forward(x, w1, b1, w2, b2, wf1, bf1, wf2, bf2, dt):
+    """x (B,1,H,W) -> (out (B, n*n+4n) fp32, saved)."""
+    b, cin, h, w = x.shape
+    x = _f32c(x)
+    c1, c2 = w1.shape[0], w2.shape[0]
+    cols1, _, _ = ops.im2col(x, planar=True, b=b, h=h, w=w, c=cin, kh=3, kw=3, stride=1, pad=1, out_dtype=dt)
+    a1 = ops.gemm(cols1, w1.reshape(c1, -1).t(), bias_n=b1, act=ACT_RELU, compute=dt, out_dtype=dt)
+    q1, i1 = ops.maxpool2_fwd(a1, b, h, w, c1)
+    h1, w1s = h // 2, w // 2
+    cols2, _, _ = ops.im2col(q1, planar=False, b=b, h=h1, w=w1s, c=c1, kh=3, kw=3, stride=1, pad=1, out_dtype=dt)
+    a2 = ops.gemm(cols2, w2.reshape(c2, -1).t(), bias_n=b2, act=ACT_RELU, compute=dt, out_dtype=dt)
+    q2, i2 = ops.maxpool2_fwd(a2, b, h1, w1s, c2)
+    h2, w2s = h1 // 2, w1s // 2
+    flat = ops.permute_pc(q2, b, h2 * w2s, c2).view(b, -1)             # x.view(x.size(0), -1) of an NCHW tensor
+    if flat.shape[1] != wf1.shape[1]:
+        raise ValueError(f"SimNN.fc1 has {wf1.shape[1]} inputs, this input gives {flat.shape[1]}")
+    hid = ops.gemm(flat, wf1.t(), bias_n=bf1, act=ACT_RELU, compute=dt)
+    out = ops.gemm(hid, wf2.t(), bias_n=bf2, compute=dt)
+    return out, (cols1, a1, i1, cols2, a2, i2, flat, hid, (b, cin, h, w, c1, c2))
+
+
+def simnn_net_backward(saved, dout, w1, w2, wf1, wf2, dt, need_dx=False):
+    """Returns (dw1, db1, dw2, db2, dwf1, dbf1, dwf2, dbf2, dx or None)."""
+    cols1, a1, i1, cols2, a2, i2, flat, hid, (b, cin, h, w, c1, c2) = saved
+    h1, w1s, h2, w2s = h // 2, w // 2, h // 4, w // 4
+    d = _f32c(dout)
+    dwf2, dbf2 = ops.gemm(d.t(), hid, compute=dt), ops.colsum(d)
+    dhid = ops.act_bwd(ops.gemm(d, wf2, compute=dt), hid, act=ACT_RELU)
+    dwf1, dbf1 = ops.gemm(dhid.t(), flat, compute=dt), ops.colsum(dhid)
+    dflat = ops.gemm(dhid, wf1, compute=dt, out_dtype=dt)                                 # (B, c2*P) channel-major
+    dq2 = ops.permute_pc(dflat, b, c2, h2 * w2s).view(b * h2 * w2s, c2)
+    da2 = ops.act_bwd(ops.maxpool2_bwd(dq2, i2, b, h1, w1s, c2), a2, act=ACT_RELU)
+    dw2, db2 = ops.gemm(da2.t(), cols2, compute=dt).view(w2.shape), ops.colsum(da2)
+    dcols2 = ops.gemm(da2, w2.reshape(c2, -1), compute=dt, out_dtype=F32)
+    dq1 = ops.col2im(dcols2, b=b, h=h1, w=w1s, c=c1, kh=3, kw=3, stride=1, pad=1, oh=h1, ow=w1s,
+                     out_dtype=dt).view(b * h1 * w1s, c1)
+    da1 = ops.act_bwd(ops.maxpool2_bwd(dq1, i1, b, h, w, c1), a1, act=ACT_RELU)
+    dw1, db1 = ops.gemm(da1.t(), cols1, compute=dt).view(w1.shape), ops.colsum(da1)
+    dx = None
+    if need_dx:
+        dcols1 = ops.gemm(da1, w1.reshape(c1, -1), compute=dt, out_dtype=F32)
+        dx = ops.col2im(dcols1, b=b, h=h, w=w, c=cin, kh=3, kw=3, stride=1, pad=1, oh=h, ow=w, out_dtype=F32,
+                        planar=True)
+    return dw1, db1, dw2, db2, dwf1, dbf1, dwf2, dbf2, dx
+
+
+class SimnnNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, wf1, bf1, wf2, bf2, dt):
+        ps = [p.detach() for p in (w1, b1, w2, b2, wf1, bf1, wf2, bf2)]
+        out, saved = simnn_net_forward(x, *ps, dt)
+        ctx.saved, ctx.ps, ctx.dt, ctx.need_dx = saved, ps, dt, x.requires_grad
+        ctx.x_shape, ctx.x_dtype = x.shape, x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        w1, _, w2, _, wf1, _, wf2, _ = ctx.ps
+        *grads, dx = simnn_net_backward(ctx.saved, dout, w1, w2, wf1, wf2, ctx.dt, ctx.need_dx)
+        if dx is not None:
+            dx = dx.view(ctx.x_shape).to(ctx.x_dtype)
+        return (dx, *grads, None)

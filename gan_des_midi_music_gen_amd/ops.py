@@ -73,15 +73,30 @@ def _call(name, *args):
 
 
 _ws_cache = {}
+_ws_retired = []          # superseded buffers a captured hipGraph may still point into (never freed)
+_ws_pinned = set()        # keys that were used while a stream capture was in progress
 
 
 def workspace(nbytes, device):
-    """Grow-only per-device scratch buffer; safe because every consumer is ordered on the same stream."""
+    """Grow-only scratch buffer per (device, stream); safe because every consumer is ordered on the same stream.
+
+    A captured hipGraph has the address of the buffer it saw baked in.  A buffer that was handed out during a capture
+    is therefore never released: when a later (eager) call needs more room the old buffer is retired, not freed --
+    the graph keeps writing into memory that is still ours.  Growing INSIDE a capture is refused (the allocation would
+    come from the graph's private pool and later eager launches on the same stream would share it)."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    capturing = torch.cuda.is_current_stream_capturing()
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if capturing and buf is not None:
+            raise GdmError(f"workspace for stream {key[1]:#x} has to grow from {buf.numel()} to {nbytes} bytes inside "
+                           "a graph capture: run the step once eagerly (same shapes) before capturing")
+        if buf is not None and key in _ws_pinned:
+            _ws_retired.append(buf)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
+    if capturing:
+        _ws_pinned.add(key)
     return buf
 
 
@@ -348,6 +363,17 @@ def simnn_conv1_bwd_weight(dp1, code1, x, out=None, accumulate=False):
     return dw, db
 
 
+def simnn_conv1_bwd_data(dp1, code1, w, h, wd):
+    """Gradient w.r.t. the (B,H,W) spectrogram input from dp1 (B,H1,W1,16), conv1's pool/ReLU codes and weight."""
+    _need_gpu(dp1, code1, w)
+    assert dp1.is_contiguous() and code1.is_contiguous() and w.is_contiguous() and w.numel() == 64
+    b = dp1.shape[0]
+    assert dp1.shape == (b, (h + 1) // 2, (wd + 1) // 2, 16) and code1.shape == dp1.shape[:3]
+    dx = torch.empty((b, h, wd), dtype=torch.float32, device=dp1.device)
+    _call("gdm_simnn_conv1_bwd_data", _p(dp1), _p(code1), _p(w), b, h, wd, _p(dx), gdm_dtype(dp1), _stream())
+    return dx
+
+
 def simnn_head(h1, w2, b2, n0, y0, y1, *, loss_out, accumulate_loss=False, want_grad=True, grad_out=None):
     """Fused fc2 + sigmoid + BCE(+backward) of model 1's discriminator head.
 
@@ -485,6 +511,68 @@ def permute_pc(src, b, p, c, out_dtype=None, out=None):
                           device=src.device)
     assert out.is_contiguous() and out.numel() == b * p * c
     _call("gdm_permute_pc", _p(src), gdm_dtype(src), b, p, c, _p(out), gdm_dtype(out), _stream())
+    return out
+
+
+def maxpool2_fwd(x, b, h, w, c, want_idx=True):
+    """x (B*H*W, C) channels-last -> (out (B*(H//2)*(W//2), C), idx uint8 or None)."""
+    _need_gpu(x)
+    assert x.is_contiguous() and x.numel() == b * h * w * c
+    oh, ow = h // 2, w // 2
+    out = torch.empty((b * oh * ow, c), dtype=x.dtype, device=x.device)
+    idx = torch.empty((b * oh * ow, c), dtype=torch.uint8, device=x.device) if want_idx else None
+    _call("gdm_maxpool2_fwd", _p(x), gdm_dtype(x), b, h, w, c, _p(out), _p(idx), _stream())
+    return out, idx
+
+
+def maxpool2_bwd(dout, idx, b, h, w, c):
+    """dout (B*(H//2)*(W//2), C) -> dx (B*H*W, C)."""
+    _need_gpu(dout, idx)
+    assert dout.is_contiguous() and idx.is_contiguous() and dout.numel() == b * (h // 2) * (w // 2) * c
+    dx = torch.empty((b * h * w, c), dtype=dout.dtype, device=dout.device)
+    _call("gdm_maxpool2_bwd", _p(dout), gdm_dtype(dout), _p(idx), b, h, w, c, _p(dx), _stream())
+    return dx
+
+
+# ---- DES-matrix prologue kernels (matrix_sim_process.py of both models) -----------------------------------------------
+def _des_view(g, s):
+    """(B,S,S) / (B,1,S,S) fp32 device tensor -> (tensor, B, sample stride in floats); samples must be dense (S,S)."""
+    _need_gpu(g)
+    if g.dim() == 4:
+        assert g.shape[1] == 1, g.shape
+        g = g[:, 0]
+    assert g.dim() == 3 and g.shape[1:] == (s, s) and g.dtype == torch.float32, (g.shape, g.dtype)
+    if g.stride(2) != 1 or g.stride(1) != s:
+        g = g.contiguous()
+    return g, g.shape[0], (g.stride(0) if g.shape[0] > 1 else s * s)
+
+
+def des_scan(g, s, dim, *, threshold=None, note_mod=False, norm_aux=False):
+    """Returns dict: thr_mask (B,S) u8 or None, instruments, note_levels (B,dim) i32, zero_mask (B,dim) i64 (bit
+    pattern of a u64), aux (B,2,dim) fp32 or None, flags (B) i32 -- all device tensors."""
+    g, b, stride = _des_view(g, s)
+    dev = g.device
+    thr_mask = torch.empty((b, s), dtype=torch.uint8, device=dev) if threshold is not None else None
+    inst = torch.empty((b, dim), dtype=torch.int32, device=dev)
+    notes = torch.empty((b, dim), dtype=torch.int32, device=dev)
+    zmask = torch.empty((b, dim), dtype=torch.int64, device=dev)
+    aux = torch.empty((b, 2, dim), dtype=torch.float32, device=dev) if norm_aux else None
+    flags = torch.empty(b, dtype=torch.int32, device=dev)
+    _call("gdm_des_scan", _p(g), stride, b, s, dim, float(threshold if threshold is not None else 0.0),
+          1 if note_mod else 0, 1 if norm_aux else 0, _p(thr_mask), _p(inst), _p(notes), _p(zmask), _p(aux), _p(flags),
+          _stream())
+    return {"thr_mask": thr_mask, "instruments": inst, "note_levels": notes, "zero_mask": zmask, "aux": aux,
+            "flags": flags}
+
+
+def des_routing(g, s, dim, src_mask, residue_col):
+    """src_mask (B,dim) u8, residue_col (B,dim) i32 device tensors -> routing matrices (B,dim,dim) fp64 (device)."""
+    g, b, stride = _des_view(g, s)
+    _need_gpu(src_mask, residue_col)
+    assert src_mask.shape == (b, dim) and src_mask.dtype == torch.uint8 and src_mask.is_contiguous()
+    assert residue_col.shape == (b, dim) and residue_col.dtype == torch.int32 and residue_col.is_contiguous()
+    out = torch.empty((b, dim, dim), dtype=torch.float64, device=g.device)
+    _call("gdm_des_routing", _p(g), stride, b, s, dim, _p(src_mask), _p(residue_col), _p(out), _stream())
     return out
 
 

@@ -26,14 +26,17 @@ class FlatBuffers:
 
     Physical layout of the gradient bucket (what the data-parallel exchange sees):
 
-        [ extra scalars (loss slots) | gradients of the small parameters | gradient of the largest parameter ]
+        [ rank-local scalars | reduced scalars | gradients of the small parameters | gradient of the largest parameter ]
 
     so that the exchange can be split in two contiguous collectives: the big tail (model 1: fc1.weight, 99.9 % of the
-    bytes) as soon as its gradient exists -- overlapped with the convolution backward -- and the small head (+ the loss
-    scalar) at the end.  ``views`` / ``grad_views`` keep the caller's parameter order.
+    bytes) as soon as its gradient exists -- overlapped with the convolution backward -- and the small head (the
+    reduced scalars = the discriminator loss + the small gradients) at the end.  The first ``local`` of the ``extra``
+    scalar slots are NEVER part of a collective (gen_loss lives there: under the pipelined schedule it is written
+    before the exchange of the following iteration and must not be summed over ranks).  ``views`` / ``grad_views`` keep
+    the caller's parameter order.
     """
 
-    def __init__(self, params, extra=0):
+    def __init__(self, params, extra=0, local=0):
         params = [p for p in params]
         assert params, "no parameters"
         dev = params[0].device     # the buffers can be laid out anywhere; the fused step itself needs a HIP device
@@ -43,6 +46,8 @@ class FlatBuffers:
         order = [i for i in range(len(params)) if i != big] + [big]
         self.n_small = self.numel - params[big].numel()
         self.n_extra = extra
+        self.n_local = local
+        assert 0 <= local <= extra
         self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
         self.bucket = torch.zeros(extra + self.numel, dtype=torch.float32, device=dev)   # extra | small | big
         self.extra = self.bucket[:extra]
@@ -71,21 +76,31 @@ class FlatBuffers:
     def bucket_big(self):
         return self.bucket[self.n_extra + self.n_small:]
 
-    def bucket_head(self, n_scalars=1):
-        """[loss slots | small gradients]; only the first ``n_scalars`` loss slots are meaningful across ranks."""
-        return self.bucket[: self.n_extra + self.n_small]
+    def bucket_head(self):
+        """[reduced scalars | small gradients] -- starts after the rank-local scalars."""
+        return self.bucket[self.n_local: self.n_extra + self.n_small]
+
+    def bucket_reduced(self):
+        """Everything that crosses ranks, as one contiguous piece: [reduced scalars | small | big gradients]."""
+        return self.bucket[self.n_local:]
+
+    def sync_hyper(self, lr, betas, eps, grad_scale=1.0):
+        """Bring the device hyper-parameter record up to date (lr schedule, ...) WITHOUT touching the step counter;
+        a captured graph reads the record, so ``replay`` calls this before every launch."""
+        want = (float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale))
+        if self._hyper is not None and want != self._hyper_host:
+            if torch.cuda.is_current_stream_capturing():
+                raise ops.GdmError("optimizer hyper-parameters changed inside a captured step: re-capture the graph")
+            self._hyper[1:6].copy_(torch.tensor(want, dtype=torch.float32), non_blocking=False)
+            self._hyper_host = want
+        return want
 
     def adam(self, lr, betas, eps, grad_scale=1.0):
         """One fused Adam launch over the flat buffer.  Step counter and hyper-parameters live in an 8-float device
         record (so a captured hipGraph replays correctly); the host only rewrites it when lr/scale change."""
-        want = (float(lr), float(betas[0]), float(betas[1]), float(eps), float(grad_scale))
+        want = self.sync_hyper(lr, betas, eps, grad_scale)
         if self._hyper is None:
             self._hyper = ops.adam_hyper(self.flat.device, *want, step=self.step_count)
-            self._hyper_host = want
-        elif want != self._hyper_host:
-            if torch.cuda.is_current_stream_capturing():
-                raise ops.GdmError("optimizer hyper-parameters changed inside a captured step: re-capture the graph")
-            self._hyper[1:6].copy_(torch.tensor(want, dtype=torch.float32), non_blocking=False)
             self._hyper_host = want
         self.step_count += 1
         ops.adam_step_dev(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self._hyper)
@@ -98,9 +113,12 @@ class _TrainerBase:
         self.elide = elide_dead_backward
         self.pg = process_group
         self.world = dp.world_size(process_group)
-        self.d = FlatBuffers(d_params, extra=4)        # extra[0] = disc_loss (rides the all-reduce), [1] = gen_loss
-        self.loss_d = self.d.extra[0:1]
-        self.loss_g = self.d.extra[1:2]
+        # extra[0] = gen_loss (rank-local, never reduced: the pipelined schedule writes it before the NEXT iteration's
+        # exchange), [1:4] rank-local scratch; extra[4] = disc_loss (rides the all-reduce), [5:8] reduced padding so
+        # that the reduced range and the gradients start on 16-byte boundaries
+        self.d = FlatBuffers(d_params, extra=8, local=4)
+        self.loss_g = self.d.extra[0:1]
+        self.loss_d = self.d.extra[4:5]
         self.iterations = 0
 
     def _reduce_big_async(self):
@@ -111,18 +129,52 @@ class _TrainerBase:
         # head of the bucket = [disc_loss | small gradients]: SUM here, 1/world folded into Adam (and the loss read-out)
         pending = getattr(self, "_pending", None)
         if pending is None:
-            dp.allreduce_bucket_(self.d.bucket, self.d.bucket.numel(), self.pg)     # everything in one collective
+            red = self.d.bucket_reduced()
+            dp.allreduce_bucket_(red, red.numel(), self.pg)                         # everything in one collective
         else:
             dp.allreduce_bucket_(self.d.bucket_head(), self.d.bucket_head().numel(), self.pg)
             pending.wait()                                                          # current stream waits for the tail
             self._pending = None
         self.d.adam(self.lr, self.betas, self.eps, grad_scale=1.0 / self.world)
 
+    def _sync_hyper(self):
+        self.d.sync_hyper(self.lr, self.betas, self.eps, 1.0 / self.world)
+
+    @torch.no_grad()
+    def load_discriminator_state(self, params=None, exp_avg=None, exp_avg_sq=None, step=None):
+        """Overwrite the discriminator's parameters and/or Adam state in place (lists in the trainer's parameter
+        order; resume from a checkpoint that kept optimizer state, teacher-forced parity tests).  Storage does not
+        move, so a captured graph stays valid; the packed / permuted operands derived from the weights are rebuilt."""
+        d = self.d
+        for src, flat in ((params, d.flat), (exp_avg, d.exp_avg), (exp_avg_sq, d.exp_avg_sq)):
+            if src is None:
+                continue
+            assert len(src) == len(d.views)
+            for v, s_ in zip(d.views, src):
+                off = (v.data_ptr() - d.flat.data_ptr()) // 4
+                flat[off:off + v.numel()].copy_(s_.detach().reshape(-1).to(flat.device, torch.float32))
+        if step is not None:
+            d.step_count = int(step)
+            if d._hyper is not None:
+                d._hyper.view(torch.int32)[0:1].copy_(torch.tensor([int(step)], dtype=torch.int32))
+        if params is not None:
+            self._refresh_operands()
+
     def disc_loss_value(self):
+        """Global-batch mean of the last discriminator loss (the SUM over ranks rode the gradient all-reduce)."""
         return self.loss_d.item() / self.world
 
     def gen_loss_value(self):
+        """THIS RANK's batch mean of the last generator loss (it is computed after the exchange and stays local)."""
         return self.loss_g.item()
+
+    def gen_loss_global(self):
+        """Global-batch mean of the last generator loss.  A collective: every rank has to call it."""
+        if self.world == 1:
+            return self.loss_g.item()
+        t = self.loss_g.clone()
+        dp.allreduce_bucket_(t, 1, self.pg)
+        return t.item() / self.world
 
 
 class SimnnTrainer(_TrainerBase):
@@ -154,13 +206,19 @@ class SimnnTrainer(_TrainerBase):
         self._side = None
         self._graph = None
         self._scratch_grads = None
-        self._pending_fake = None  # step_pipelined: fake batch whose generator half has not run yet
+        self._pending_fake = None  # step_pipelined: fake batch whose generator half has not run yet (= _fake_buf)
+        self._fake_buf = None      # trainer-owned copy of that batch
         self._prepared_stale = False
 
     def invalidate_weights(self):
         """Call after changing discriminator weights from outside (e.g. load_state_dict)."""
         self._prepared = None
         self._prepared_stale = False
+
+    def _refresh_operands(self):
+        if self._prepared is not None:
+            Fn.simnn_disc_prepare(self.d.views[2], self.d.views[4], self.dt, out=self._prepared)
+            self._prepared_stale = False
 
     def _gen_state(self):
         g = self.gen
@@ -212,7 +270,9 @@ class SimnnTrainer(_TrainerBase):
     def step(self, real, noise, fake):
         """real (B,H,W) fp32 on the device; noise (B,noise_dim,1,1); fake: (B,H,W) tensor, or a callable
         ``fake(generated (B,1,20,20) device tensor) -> (B,H,W) tensor`` standing in for matrix_to_wav (SIMNN.py:301).
-        Returns (disc_loss, gen_loss) as 1-element device tensors (this rank's batch means)."""
+        Returns (disc_loss, gen_loss) as 1-element device tensors: gen_loss is this rank's batch mean; disc_loss is this
+        rank's batch mean on one rank and the SUM over ranks of the batch means with world > 1 (it rides the gradient
+        all-reduce; ``disc_loss_value()`` divides by world)."""
         if self._pending_fake is not None:
             self.flush()
         dt = self.dt
@@ -360,23 +420,30 @@ class SimnnTrainer(_TrainerBase):
                 main.wait_stream(side[1])
         else:
             ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
-        if pending is not None:
-            # generator half of the previous iteration: reads the weights / prepared operands that stay untouched until
-            # this call's Adam, writes only gen_loss and scratch buffers
-            if side:
-                side[2].wait_stream(main)
-            with torch.cuda.stream(side[2] if side else main):
+        # generator half of the previous iteration: reads the weights / prepared operands that stay untouched until
+        # this call's Adam, writes only gen_loss and scratch buffers.  Then, on the same stream (so after the half's last
+        # read of it), the trainer's own copy of the fake batch is refreshed with THIS iteration's: the caller may
+        # refill ``fake`` as soon as this call returns (loaders / bridges that reuse their output buffer do).
+        if side:
+            side[2].wait_stream(main)
+        with torch.cuda.stream(side[2] if side else main):
+            if pending is not None:
                 self._generator_half(pending, keep)
+            if self._fake_buf is None or self._fake_buf.shape != fake.shape:
+                if torch.cuda.is_current_stream_capturing():
+                    raise ops.GdmError("step_pipelined saw a new batch geometry inside a graph capture")
+                self._fake_buf = torch.empty_like(fake)
+            self._fake_buf.copy_(fake)
         hid, saved = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1, code1))
         _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 0.9, 0.1, loss_out=self.loss_d, grad_out=(gv[6], gv[7], gv[5]))
         self._d_backward(saved, dh, pack, wf1p, gv, (real, fake), keep)
-        if side and pending is not None:
+        if side:
             main.wait_stream(side[2])
         self._reduce_and_step()
         self._prepared_stale = True
         if side:
             main.wait_stream(side[0])
-        self._pending_fake = fake
+        self._pending_fake = self._fake_buf
         self.iterations += 1
         del keep
         return self.loss_d, self.loss_g
@@ -414,10 +481,14 @@ class SimnnTrainer(_TrainerBase):
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             fn(*self._static)      # pipelined: the captured call finds a pending half and leaves one, like every replay
+        self.d.step_count -= 1     # the captured call did not execute: the device-side step counter did not move
+        self.iterations -= 1
         return self._graph
 
     def replay(self):
+        self._sync_hyper()         # lr schedule etc.: the captured Adam reads the device record
         self._graph.replay()
+        self.d.step_count += 1
         self.iterations += 1
         return self.loss_d, self.loss_g
 
@@ -443,6 +514,10 @@ class MmganTrainer(_TrainerBase):
 
     def invalidate_weights(self):
         self._pack = None
+
+    def _refresh_operands(self):
+        if self._pack is not None:
+            ops.dcnn_pack(*self.d.views, self._pack_t, out=self._pack)
 
     @staticmethod
     def _layers(gen):
@@ -489,7 +564,7 @@ class MmganTrainer(_TrainerBase):
         sides = self._gen_stream
         # (a branch forked at the very root of a captured graph was observed to run before, not beside, the main
         # branch: fork after a first small launch on the main stream)
-        self.d.extra[2:].zero_()
+        self.d.extra[1:4].zero_()
         # --- D step (network_tests.py:293-308)
         for sd in sides:
             sd.wait_stream(main)
@@ -502,6 +577,7 @@ class MmganTrainer(_TrainerBase):
         if fused:
             if self._pack is None:
                 self._pack = ops.dcnn_pack(w1, b1, w2, b2, wf, bf, t)
+                self._pack_t = t
             fa = Fn._f32c(fake_a)
             # batch [fake ; real] with labels 0 / 1 (304-305); real_data is read as two planes: no stack/permute copy
             ops.dcnn_fused(fa, (Fn._f32c(piano_roll), Fn._f32c(durations)), t, 0.0, 1.0, self._pack,
@@ -516,7 +592,7 @@ class MmganTrainer(_TrainerBase):
             dl = torch.empty(2 * b, dtype=torch.float32, device=dev)
             ops.bce_with_logits(lg[:b], 0.0, loss_out=self.loss_d, dx_out=dl[:b])
             ops.bce_with_logits(lg[b:], 1.0, loss_out=self.loss_d, dx_out=dl[b:], accumulate_loss=True)
-            grads = Fn.dcnn_backward(saved, dl, w2, wf, dt)
+            grads = Fn.dcnn_backward(saved, dl, w2, wf, dt)[:6]
             for gview, g in zip(gv, grads):
                 gview.copy_(g.view(gview.shape))
         self._reduce_and_step()
@@ -567,10 +643,14 @@ class MmganTrainer(_TrainerBase):
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
             self.step(*args[:7], g1_in_a=g1_in_a, g1_in_b=g1_in_b)
+        self.d.step_count -= 1     # the captured call did not execute: the device-side step counter did not move
+        self.iterations -= 1
         return self._graph
 
     def replay(self):
+        self._sync_hyper()         # lr schedule etc.: the captured Adam reads the device record
         self._graph.replay()
+        self.d.step_count += 1
         self.iterations += 1
         return self.loss_d, self.loss_g
 

@@ -31,6 +31,7 @@ enum { GDM_OK = 0, GDM_EINVAL = -1, GDM_ELAUNCH = -2, GDM_EWORKSPACE = -3 };
 const char* gdm_last_error(void);
 int gdm_version(void);          /* 1000*major + minor */
 const char* gdm_arch(void);     /* "gfx950" */
+int gdm_build_flavor(void);     /* 0 = shipped flags; 1 = built with experiment switches (GDM_HIPCC_FLAGS): not benchable */
 
 /* ---- dense layers (aten::addmm / aten::mm: nn.Linear fwd, dX, dW; ConvTranspose2d as GEMM) ---------------------
  * C[m,n] = act( sum_k A[m,k]*B[k,n] + bias_n[n] + bias_m[m] ), arbitrary element strides (transposes are free).
@@ -139,6 +140,11 @@ size_t gdm_simnn_conv1_bwd_weight_workspace_bytes(int B, int H, int W);
 int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1, const float* x, int B, int H, int W,
                                float* dw, float* db, int dtype, int accumulate, void* workspace, size_t workspace_bytes,
                                void* stream);
+/* dx (B,H,W) fp32 = gradient w.r.t. the discriminator's spectrogram input (aten::convolution_backward's input
+ * gradient of SIMNN.py:136 behind the ReLU/pool routing of code1); dp1 (B,H1,W1,16) as written by
+ * gdm_simnn_conv2_bwd_fused(dp1_or_null != NULL) or gdm_simnn_conv2_bwd_data; w = conv1.weight (16,1,2,2). */
+int gdm_simnn_conv1_bwd_data(const void* dp1, const uint64_t* code1, const float* w, int B, int H, int W, float* dx,
+                             int dtype, void* stream);
 
 /* head of model 1's discriminator, forward + loss + backward in one launch (SIMNN.py:140-141, 289/311/329):
  * h1 (n,128) fp32 = relu(fc1) -> prob (n) = sigmoid(fc2), loss[0] (+)= sum over the two label halves of the batch
@@ -197,6 +203,34 @@ int gdm_col2im(const void* cols, int cols_dtype, int B, int H, int W, int C, int
 /* dst (B,C,P) = src (B,P,C) transposed per batch element, with dtype conversion (channels-last <-> channel-major
  * flatten order: activations, and fc1's weight / weight gradient viewed as (128, 32, H2*W2) <-> (128, H2*W2, 32)). */
 int gdm_permute_pc(const void* src, int src_dtype, int B, int P, int C, void* dst, int dst_dtype, void* stream);
+
+/* aten::max_pool2d_with_indices / its backward, kernel 2 stride 2 (floor), channels-last (B,H,W,C) -> (B,H/2,W/2,C)
+ * (F.max_pool2d(x, 2, 2) of the SimNN branch, GAN_DES/SIMNN.py:156,158).  idx: window position 0..3 of the first
+ * maximum in scan order, one byte per output element (NULL: forward only).                                          */
+int gdm_maxpool2_fwd(const void* src, int dtype, int B, int H, int W, int C, void* dst, uint8_t* idx_or_null,
+                     void* stream);
+int gdm_maxpool2_bwd(const void* dout, int dtype, const uint8_t* idx, int B, int H, int W, int C, void* dx,
+                     void* stream);
+
+/* ---- batched DES-matrix prologue (numpy head of matrix_to_midi, MMGAN_MIDI_DES/matrix_sim_process.py:33-117, and of
+ * matrix_to_wav, GAN_DES/matrix_sim_process.py:21-95): generated matrix -> what simulation_v3.Sim is constructed from.
+ * g: B samples of an (S,S) fp32 matrix, sample_stride floats apart (the generator output in place); dim = number of
+ * DES nodes (S - 3 / S - 5); rows dim.. are parameter rows.  The reference interleaves this arithmetic with draws from
+ * numpy's global RNG whose consumption depends on the data, so the host advances the stream between the two calls:
+ * gdm_des_scan    |m| -> thr_mask (B,S) u8 = |m[dim][x]| > threshold (NULL: skip); instruments (B,dim) i32 =
+ *                 int(|m[dim+1][i]| * 126); note_levels (B,dim) i32 = int(|m[dim+2][i]| * 126), with note_mod:
+ *                 max(0, . % 128); zero_mask (B,dim) u64, bit x of row i set iff |m[i][x]| == 0 (x < dim);
+ *                 norm_aux: aux (B,2,dim) fp32 = rows dim+3, dim+4 divided by their sequential float32 sum over all S
+ *                 entries (model 1's distribution rows); flags (B) i32, bit 0 = the sample holds a non-finite value.
+ * gdm_des_routing src_mask (B,dim) u8 (1 = source node), residue_col (B,dim) i32 (column that absorbs 1 - sum(row);
+ *                 < 0: none) -> out (B,dim,dim) fp64: source columns and diagonal zeroed, rows divided by their
+ *                 float64 sum in numpy's pairwise order (0/0 -> 0), residue added, diagonal +1 (source) / -1 (server).
+ * S <= 64.  Results are bit-identical to numpy's on finite inputs (tests/golden/des_prologue.npz).                  */
+int gdm_des_scan(const float* g, int64_t sample_stride, int B, int S, int dim, float threshold, int note_mod,
+                 int norm_aux, uint8_t* thr_mask_or_null, int32_t* instruments, int32_t* note_levels,
+                 uint64_t* zero_mask, float* aux_or_null, int32_t* flags, void* stream);
+int gdm_des_routing(const float* g, int64_t sample_stride, int B, int S, int dim, const uint8_t* src_mask,
+                    const int32_t* residue_col, double* out, void* stream);
 
 /* ---- mel-spectrogram featuriser (GAN_DES/util.py:37-61: torchaudio MelSpectrogram + AmplitudeToDB) --------------
  * The producer of model 1's discriminator input.  DFT and mel filter bank are gdm_gemm calls in exact fp32 (window

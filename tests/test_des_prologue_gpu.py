@@ -1,0 +1,137 @@
+"""GPU: the batched DES-matrix prologue (gan_des_midi_music_gen_amd.matrix_sim_process, csrc/des_prologue.hip) against
+(a) the golden vectors recorded from the reference's own matrix_to_midi / matrix_to_wav (tests/golden/des_prologue.npz)
+and (b) the live CPU oracle (oracle/des_prologue.py) on larger seeded batches.  Bar: integers, seeds and the position
+of numpy's global RNG exact; float64 routing matrices BIT-identical (stated bound 1e-12, measured 0)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gan_des_midi_music_gen_amd import matrix_sim_process as msp, ops  # noqa: E402
+from oracle import des_prologue as odp  # noqa: E402  (checker only)
+
+from helpers import load_golden  # noqa: E402
+
+DEV = "cuda"
+
+
+def _same(spec, want, what):
+    assert np.array_equal(spec.sim_matrix, want["sim_matrix"]), (what, np.abs(spec.sim_matrix - want["sim_matrix"]).max())
+    got = np.array([[float(d[1]), float(d[2])] for d in spec.distributions])
+    ref = np.array([[float(d[1]), float(d[2])] for d in want["distributions"]])
+    assert np.array_equal(got, ref), what
+    assert np.array_equal(np.asarray(spec.seeds), np.asarray(want["seeds"])), what
+    assert spec.num_customers == want["num_customers"] and spec.max_sim_time == want["max_sim_time"], what
+    assert list(spec.queue_list) == list(want["queue_list"])
+    assert np.array_equal(np.asarray(spec.instruments, dtype=np.float64), np.asarray(want["instruments"], dtype=np.float64))
+    assert np.array_equal(spec.note_levels, want["note_levels"]), what
+
+
+def _golden_specs(g, pre):
+    n = g[f"{pre}/sim_matrix"].shape[0]
+    return [{"sim_matrix": g[f"{pre}/sim_matrix"][b], "distributions": [["normal", *row] for row in g[f"{pre}/dist"][b]],
+             "seeds": g[f"{pre}/seeds"][b], "num_customers": int(g[f"{pre}/num_customers"][b]),
+             "max_sim_time": float(g[f"{pre}/max_sim_time"][b]), "queue_list": list(g[f"{pre}/queue_list"]),
+             "instruments": g[f"{pre}/instruments"][b], "note_levels": g[f"{pre}/note_levels"][b]} for b in range(n)]
+
+
+def test_matrix_to_midi_prologue_matches_the_reference_recording():
+    g = load_golden("des_prologue.npz")
+    for case in (0, 1):
+        pre = f"midi{case}"
+        inst = int(g[f"{pre}/instrument"])
+        g1 = torch.from_numpy(g[f"{pre}/g1"][:, None]).to(DEV)
+        g2 = torch.from_numpy(g[f"{pre}/g2"]).to(DEV)
+        seen = []
+        np.random.seed(int(g[f"{pre}/np_seed"]))
+        rolls, failed = msp.matrix_to_midi(g1, g2, adj_size=(64, 64), instrument=None if inst < 0 else inst, start=100,
+                                           end=150, count=1, simulate=lambda spec, **kw: seen.append((spec, kw)))
+        assert np.random.randint(0, 2 ** 31 - 1) == int(g[f"{pre}/rng_after"]), "global RNG stream position"
+        # every simulation "failed" (the stand-in returns None, as the recorder's did): zero rolls, all counted
+        assert failed == int(g[f"{pre}/failed"]) and len(rolls) == int(g[f"{pre}/n_rolls"])
+        assert rolls[0].shape == tuple(g[f"{pre}/roll_shape"]) and not rolls[0].any()
+        for b, (want, (spec, kw)) in enumerate(zip(_golden_specs(g, pre), seen)):
+            _same(spec, want, (pre, b))
+            assert kw["start"] == 100 and kw["end"] == 150 and kw["count"] == 1
+            assert np.array_equal(kw["gen2_tail"], g[f"{pre}/g2"][b][10:])
+
+
+def test_matrix_to_wav_prologue_matches_the_reference_recording():
+    g = load_golden("des_prologue.npz")
+    m = torch.from_numpy(g["wav/matrices"]).to(DEV)
+    seen = []
+
+    def simulate(spec, index):
+        seen.append(spec)
+        return torch.zeros(128, 216)
+
+    np.random.seed(int(g["wav/np_seed"]))
+    out = msp.matrix_to_wav(m, size=20, start=0, end=216, device="cpu", simulate=simulate)
+    assert np.random.randint(0, 2 ** 31 - 1) == int(g["wav/rng_after"])
+    assert tuple(out.shape) == tuple(g["wav/spec_shape"])
+    for b, (want, spec) in enumerate(zip(_golden_specs(g, "wav"), seen)):
+        _same(spec, want, ("wav", b))
+    assert [list(s.sources) for s in seen][2] == [4] and [list(s.sources) for s in seen][4] == [7]
+    two = g["wav/matrices"][:1].copy()
+    two[0, 15, 3], two[0, 15, 9] = 0.8, 0.95
+    with pytest.raises(ValueError):          # upstream: `x not in sources` on np.where's tuple
+        msp.wav_prologue(torch.from_numpy(two).to(DEV), size=20)
+    oob = g["wav/matrices"][:1].copy()
+    oob[0, 15, :] = 0.1
+    oob[0, 15, 17] = 0.9
+    with pytest.raises(IndexError):          # upstream: sim_matrix[:, 17] on a 15-column view
+        msp.wav_prologue(torch.from_numpy(oob).to(DEV), size=20)
+
+
+@pytest.mark.parametrize("b", [1, 37, 256])
+def test_prologue_vs_live_oracle_on_seeded_batches(b):
+    """Generator-shaped batches (sigmoid outputs, (B,1,64,64) / (B,20,20)), incl. the benchmark batch 256, exact zeros
+    and negative entries; the device path and the oracle start from the same np.random seed."""
+    r = np.random.RandomState(1000 + b)
+    g1 = (1.0 / (1.0 + np.exp(-r.standard_normal((b, 1, 64, 64))))).astype(np.float32)
+    g1[r.random_sample(g1.shape) < 0.02] = 0.0
+    g1[r.random_sample(g1.shape) < 0.02] *= -1.0
+    g2 = (1.0 / (1.0 + np.exp(-r.standard_normal((b, 20))))).astype(np.float32)
+    np.random.seed(5)
+    want = odp.midi_prologue(g1, g2, adj_size=(64, 64), instrument=None)
+    pos = np.random.randint(0, 2 ** 31 - 1)
+    np.random.seed(5)
+    got = msp.midi_prologue(torch.from_numpy(g1).to(DEV), torch.from_numpy(g2).to(DEV), adj_size=(64, 64))
+    assert np.random.randint(0, 2 ** 31 - 1) == pos
+    for i, (s_, w) in enumerate(zip(got, want)):
+        _same(s_, w, ("midi", i))
+        assert np.allclose(s_.sim_matrix.sum(axis=1) - np.diag(s_.sim_matrix), 1.0, atol=1e-12)   # row-stochastic
+    m = (1.0 / (1.0 + np.exp(-r.standard_normal((b, 20, 20))))).astype(np.float32)
+    m[:, 15, :] = np.minimum(m[:, 15, :], 0.74)
+    m[::3, 15, 2] = 0.8                                 # every third sample: exactly one thresholded source
+    np.random.seed(6)
+    want = odp.wav_prologue(m, size=20)
+    pos = np.random.randint(0, 2 ** 31 - 1)
+    np.random.seed(6)
+    got = msp.wav_prologue(torch.from_numpy(m).to(DEV), size=20)
+    assert np.random.randint(0, 2 ** 31 - 1) == pos
+    for i, (s_, w) in enumerate(zip(got, want)):
+        _same(s_, w, ("wav", i))
+
+
+def test_prologue_edge_cases():
+    # a non-contiguous generator output (a channel slice of a wider tensor) is read in place
+    r = np.random.RandomState(3)
+    wide = torch.from_numpy(r.random_sample((4, 2, 64, 64)).astype(np.float32)).to(DEV)
+    np.random.seed(1)
+    a = msp.midi_prologue(wide[:, 1:2], torch.rand(4, 20, device=DEV), adj_size=(64, 64))
+    np.random.seed(1)
+    c = msp.midi_prologue(wide[:, 1:2].contiguous(), torch.rand(4, 20, device=DEV), adj_size=(64, 64))
+    assert all(np.array_equal(x.sim_matrix, y.sim_matrix) for x, y in zip(a, c))
+    # an all-zero row has no column to take the residue: numpy's choice([]) raises, as upstream
+    z = torch.rand(1, 1, 64, 64, device=DEV)
+    z[0, 0, 5, :] = 0.0
+    with pytest.raises(ValueError):
+        msp.midi_prologue(z, torch.rand(1, 20, device=DEV), adj_size=(64, 64))
+    bad = torch.rand(1, 1, 64, 64, device=DEV)
+    bad[0, 0, 3, 3] = float("inf")
+    with pytest.raises(ValueError):
+        msp.midi_prologue(bad, torch.rand(1, 20, device=DEV), adj_size=(64, 64))
+    with pytest.raises(ops.GdmError):
+        msp.midi_prologue(torch.rand(1, 1, 64, 64), torch.rand(1, 20), adj_size=(64, 64))      # CPU tensors: no fallback

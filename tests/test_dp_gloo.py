@@ -45,19 +45,24 @@ def _worker(rank, world, port, out_dir):
     disc = osn.Discriminator(input_hw=HW).apply(osn.weights_init)       # identical replica on every rank
     real, fake, _ = synthetic.simnn_inputs(GLOBAL_B, HW, seed=42)
     lo, hi = dp.shard_bounds(GLOBAL_B, world, rank)
-    fb = FlatBuffers(list(disc.parameters()), extra=4)
+    fb = FlatBuffers(list(disc.parameters()), extra=8, local=4)          # the trainers' layout
     loss, grads = _local_grads(disc, real[lo:hi], fake[lo:hi])
     for gv, g in zip(fb.grad_views, grads):
         gv.copy_(g)
-    fb.extra[0] = loss
+    fb.extra[4] = loss                 # disc_loss: first reduced scalar
+    fb.extra[0] = 100.0 + rank         # gen_loss slot: rank-local, no collective may touch it
     # the exchange as the trainers do it: the big tail (fc1.weight) asynchronously first, then [loss | small grads]
     pending = dp.allreduce_async_(fb.bucket_big())
     scale = dp.allreduce_bucket_(fb.bucket_head(), fb.bucket_head().numel())
     pending.wait()
     assert scale == 1.0 / world
+    assert fb.extra[0].item() == 100.0 + rank and fb.extra[1:4].abs().sum().item() == 0.0
+    # ... and the single-collective form (model 2) covers exactly the same range
+    assert fb.bucket_reduced().data_ptr() == fb.bucket_head().data_ptr()
+    assert fb.bucket_reduced().numel() == fb.bucket_head().numel() + fb.bucket_big().numel()
     if rank == 0:
         grads = torch.cat([g.reshape(-1) for g in fb.grad_views]) * scale      # caller's parameter order
-        torch.save({"grads": grads, "loss": fb.extra[0].item() * scale, "numel": fb.numel},
+        torch.save({"grads": grads, "loss": fb.extra[4].item() * scale, "numel": fb.numel},
                    os.path.join(out_dir, "dp.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -81,8 +86,8 @@ def test_flat_buffers_views_alias_parameters_and_grads():
     torch.manual_seed(1)
     disc = osn.Discriminator(input_hw=HW)
     before = [p.detach().clone() for p in disc.parameters()]
-    fb = FlatBuffers(list(disc.parameters()), extra=4)
-    assert fb.numel == sum(p.numel() for p in disc.parameters()) and fb.bucket.numel() == fb.numel + 4
+    fb = FlatBuffers(list(disc.parameters()), extra=8, local=4)
+    assert fb.numel == sum(p.numel() for p in disc.parameters()) and fb.bucket.numel() == fb.numel + 8
     params = list(disc.parameters())
     big = max(range(len(params)), key=lambda i: params[i].numel())
     off = 0
@@ -93,7 +98,8 @@ def test_flat_buffers_views_alias_parameters_and_grads():
         assert fb.views[i].data_ptr() == p.data_ptr() and fb.grad_views[i].data_ptr() == p.grad.data_ptr()
         off += p.numel()
     assert fb.bucket_big().numel() == params[big].numel() and fb.bucket_big().data_ptr() == params[big].grad.data_ptr()
-    assert fb.bucket_head().data_ptr() == fb.bucket.data_ptr() and fb.extra.data_ptr() == fb.bucket.data_ptr()
+    assert fb.bucket_head().data_ptr() == fb.bucket.data_ptr() + 16 and fb.extra.data_ptr() == fb.bucket.data_ptr()
+    assert fb.bucket_head().numel() == 4 + fb.n_small
     with pytest.raises(Exception):
         fb.adam(1e-3, (0.9, 0.999), 1e-8)      # the optimizer step is HIP-only: no CPU fallback
 

@@ -30,7 +30,7 @@ for it in range(3):
     real, fake, noise = synthetic.simnn_inputs(GB, hw, seed=900 + it, device=dev)
     dl, gl = tr.step(real[lo:hi].contiguous(), noise[lo:hi].contiguous(), fake[lo:hi].contiguous())
 torch.cuda.synchronize()
-out["simnn"] = {"d_loss": tr.disc_loss_value(), "fc1": disc.fc1.weight.detach().cpu(), "c1": disc.conv1.weight.detach().cpu(),
+out["simnn"] = {"d_loss": tr.disc_loss_value(), "g_loss": tr.gen_loss_global(), "fc1": disc.fc1.weight.detach().cpu(), "c1": disc.conv1.weight.detach().cpu(),
                 "fc2b": disc.fc2.bias.detach().cpu()}
 torch.manual_seed(0)
 gen = SIMNN.Generator().apply(SIMNN.weights_init).to(dev)
@@ -39,9 +39,11 @@ trp = SimnnTrainer(gen, disc, compute_dtype="fp32")
 for it in range(3):
     real, fake, noise = synthetic.simnn_inputs(GB, hw, seed=900 + it, device=dev)
     trp.step_pipelined(real[lo:hi].contiguous(), noise[lo:hi].contiguous(), fake[lo:hi].contiguous())
+torch.cuda.synchronize()
+g_mid = trp.gen_loss_global()      # gen_loss of the iteration before the last one: written BEFORE the last exchange
 trp.flush()
 torch.cuda.synchronize()
-out["simnn_pipelined"] = {"d_loss": trp.disc_loss_value(), "fc1": disc.fc1.weight.detach().cpu(),
+out["simnn_pipelined"] = {"d_loss": trp.disc_loss_value(), "g_loss": trp.gen_loss_global(), "g_loss_mid": g_mid, "fc1": disc.fc1.weight.detach().cpu(),
                           "c1": disc.conv1.weight.detach().cpu(), "fc2b": disc.fc2.bias.detach().cpu()}
 torch.manual_seed(0)
 mm = NT.MultiModalGAN(z_dim=50, adj_size=(64, 64), roll_size=(2, 128, 50), input_dim=50, output_dim=20, device=dev)
@@ -53,7 +55,7 @@ for it in range(2):
             d["noise1"][sl].contiguous(), d["noise2"][sl].contiguous(), d["fake_a"][sl].contiguous(),
             d["fake_b"][sl].contiguous(), g1_in_a=d["g1_in_a"][sl].contiguous(), g1_in_b=d["g1_in_b"][sl].contiguous())
 torch.cuda.synchronize()
-out["mmgan"] = {"d_loss": mt.disc_loss_value(), "fc": mm.discriminator.fc.weight.detach().cpu(),
+out["mmgan"] = {"d_loss": mt.disc_loss_value(), "g_loss": mt.gen_loss_global(), "fc": mm.discriminator.fc.weight.detach().cpu(),
                 "c2": mm.discriminator.conv2.weight.detach().cpu()}
 if rank == 0:
     torch.save(out, os.environ["GDM_OUT"])
@@ -95,7 +97,11 @@ def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path):
     for model in ("simnn", "simnn_pipelined", "mmgan"):
         a, b = one[model], two[model]
         assert abs(a["d_loss"] - b["d_loss"]) < 1e-5 * max(1.0, abs(a["d_loss"])), (model, a["d_loss"], b["d_loss"])
+        for k in [k for k in a if k.startswith("g_loss")]:
+            # gen_loss is rank-local state (never summed by the gradient exchange, also not under the pipelined
+            # schedule, which writes it before the next exchange); its global mean equals the single process's
+            assert abs(a[k] - b[k]) < 1e-5 * max(1.0, abs(a[k])), (model, k, a[k], b[k])
         for k in a:
-            if k != "d_loss":
+            if not k.endswith("_loss") and not k.startswith("g_loss"):
                 # Adam's first steps move every weight by ~lr regardless of |g|: allow a few 1e-6 of drift
                 assert (a[k] - b[k]).abs().max().item() < 3e-5, (model, k, (a[k] - b[k]).abs().max().item())

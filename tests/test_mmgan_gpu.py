@@ -91,6 +91,27 @@ def test_modules_match_golden_fp32():
         assert_summary_close(tensor_summary(p.grad), g[f"mlpd_grad/{k}"], 5e-4, 1e-7, k)
 
 
+def test_discriminator_input_gradients_match_golden_fp32():
+    """x.requires_grad_() on both discriminators (ordinary autograd modules upstream, network_tests.py:137-160)."""
+    g = load_golden("input_grads.npz")
+    mm = _mm(0)
+    mlpd = NT.Discriminator(roll_size=(2, 128, 50))
+    mm.to(DEV), mlpd.to(DEV)
+    x = torch.from_numpy(g["dcnn/x"]).to(DEV).requires_grad_(True)
+    b = x.shape[0]
+    F.binary_cross_entropy_with_logits(mm.discriminator(x).squeeze(), torch.zeros(b, device=DEV)).backward()
+    assert x.grad.shape == x.shape
+    assert rel_l2(x.grad, g["dcnn/x_grad"]) < 2e-4, rel_l2(x.grad, g["dcnn/x_grad"])
+    assert rel_l2(mm.discriminator.conv1.weight.grad, g["dcnn/conv1_weight_grad"]) < 2e-4
+    flat = torch.from_numpy(g["dcnn/x"]).reshape(b, -1).to(DEV).requires_grad_(True)
+    mlpd(flat).sum().backward()
+    assert rel_l2(flat.grad, g["mlpd/x_grad"]) < 2e-4
+    mm.discriminator.compute_dtype = "bf16"
+    x2 = torch.from_numpy(g["dcnn/x"]).to(DEV).requires_grad_(True)
+    F.binary_cross_entropy_with_logits(mm.discriminator(x2).squeeze(), torch.zeros(b, device=DEV)).backward()
+    assert rel_l2(x2.grad, g["dcnn/x_grad"]) < 5e-2
+
+
 def test_multimodal_gan_forward_contract():
     calls = []
 

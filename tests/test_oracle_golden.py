@@ -219,3 +219,44 @@ def test_checkpoint_manifests_match_oracle_keys(golden_dir):
     for rel in ("MMGAN_MIDI_DES/models/mmgan_64_64_epoch_1.pth",
                 "MMGAN_MIDI_DES/models/MAE_loss/mmgan_64_64_epoch_35.pth"):
         assert got == man[rel], rel
+
+
+# ---------------------------------------------------------------------------------------------------- DES prologue
+def _check_des_specs(specs, g, pre):
+    assert len(specs) == g[f"{pre}/sim_matrix"].shape[0]
+    for b, sp in enumerate(specs):
+        assert np.array_equal(sp["sim_matrix"], g[f"{pre}/sim_matrix"][b]), (pre, b, "routing matrix not bit-identical")
+        got_dist = np.array([[float(d[1]), float(d[2])] for d in sp["distributions"]])
+        assert np.array_equal(got_dist, g[f"{pre}/dist"][b]), (pre, b, "distributions")
+        assert all(d[0] == "normal" for d in sp["distributions"])
+        assert np.array_equal(np.asarray(sp["seeds"]), g[f"{pre}/seeds"][b])
+        assert sp["num_customers"] == int(g[f"{pre}/num_customers"][b])
+        assert sp["max_sim_time"] == float(g[f"{pre}/max_sim_time"][b])
+        assert list(sp["queue_list"]) == list(g[f"{pre}/queue_list"])
+        assert np.array_equal(np.asarray(sp["instruments"], dtype=np.float64), g[f"{pre}/instruments"][b])
+        assert np.array_equal(np.asarray(sp["note_levels"], dtype=np.float64), g[f"{pre}/note_levels"][b])
+
+
+def test_des_prologue_oracle_reproduces_the_recorded_sim_arguments():
+    """oracle/des_prologue.py against what the reference's matrix_to_midi / matrix_to_wav handed to Sim (recorded by
+    tests/golden/make_golden.py des_prologue): bit-identical float64 routing matrices, exact integers, and the global
+    numpy RNG left at the same position."""
+    from oracle import des_prologue as odp
+    g = load_golden("des_prologue.npz")
+    for case in (0, 1):
+        pre = f"midi{case}"
+        inst = int(g[f"{pre}/instrument"])
+        np.random.seed(int(g[f"{pre}/np_seed"]))
+        specs = odp.midi_prologue(g[f"{pre}/g1"][:, None], g[f"{pre}/g2"], adj_size=(64, 64),
+                                  instrument=None if inst < 0 else inst)
+        assert np.random.randint(0, 2 ** 31 - 1) == int(g[f"{pre}/rng_after"])
+        _check_des_specs(specs, g, pre)
+    np.random.seed(int(g["wav/np_seed"]))
+    specs = odp.wav_prologue(g["wav/matrices"], size=20)
+    assert np.random.randint(0, 2 ** 31 - 1) == int(g["wav/rng_after"])
+    _check_des_specs(specs, g, "wav")
+    two = g["wav/matrices"][:1].copy()
+    two[0, 15, 3], two[0, 15, 9] = 0.8, 0.95
+    assert str(g["wav/two_sources_raises"]) == "ValueError"
+    with pytest.raises(ValueError):
+        odp.wav_prologue(two, size=20)

@@ -324,5 +324,65 @@ def test_geometry_mismatch_is_a_clear_error():
     disc = SIMNN.Discriminator().to(DEV)
     with pytest.raises(ValueError):
         disc(torch.zeros(2, 128, 256, device=DEV))
-    with pytest.raises(NotImplementedError):
-        SIMNN.SimNN(4)(torch.zeros(1, 1, 128, 128))
+
+
+def test_discriminator_input_gradient_matches_golden_fp32():
+    """x.requires_grad_(): the module is an ordinary autograd citizen like the reference's (SIMNN.py:129-142)."""
+    g = load_golden("input_grads.npz")
+    _, disc = _build(0, False)
+    disc.to(DEV)
+    x = torch.from_numpy(g["simnn/x"]).to(DEV).requires_grad_(True)
+    b = x.shape[0]
+    F.binary_cross_entropy_with_logits(disc(x).reshape(-1), torch.full((b,), 0.9, device=DEV)).backward()
+    assert x.grad.shape == x.shape
+    assert rel_l2(x.grad, g["simnn/x_grad"]) < 2e-4, rel_l2(x.grad, g["simnn/x_grad"])
+    assert rel_l2(disc.conv1.weight.grad, g["simnn/conv1_weight_grad"]) < 2e-4
+    # bf16 activations: same gradient within the stated bf16 gradient bound
+    disc.compute_dtype = "bf16"
+    x2 = torch.from_numpy(g["simnn/x"]).to(DEV).requires_grad_(True)
+    F.binary_cross_entropy_with_logits(disc(x2).reshape(-1), torch.full((b,), 0.9, device=DEV)).backward()
+    assert rel_l2(x2.grad, g["simnn/x_grad"]) < 5e-2
+
+
+def test_simnn_net_matches_golden_and_reference_shape_test():
+    """SimNN (GAN_DES/SIMNN.py:145-170).  Golden: same constructor seed -> same conv/fc2 weights (digests), same seed
+    right before forward -> same re-created fc1 -> same five outputs.  Then the reference's own ad-hoc test
+    (test_SimNN, SIMNN.py:218-231: output shapes for random input sizes) at sizes that fit."""
+    g = load_golden("simnn_net.npz")
+    torch.manual_seed(7)
+    net = SIMNN.SimNN(6)
+    for k, v in net.state_dict().items():
+        assert weight_digest(v) == g[f"digest/{k}"], k
+    net.to(DEV)
+    x = torch.from_numpy(g["x"]).to(DEV)
+    torch.manual_seed(123)
+    outs = net(x)
+    assert weight_digest(net.fc1.weight) == g["fc1_weight_digest"] and net.fc1.in_features == int(g["fc1_in_features"])
+    for name, o in zip(("matrix", "array1", "array2", "array3", "array4"), outs):
+        _close(o, g[name], 2e-5, f"SimNN {name}")
+    # backward (module completeness) against torch CPU autograd on the same weights
+    ref = torch.nn.Sequential()       # plain fp32 restatement of the op chain
+    xc = torch.from_numpy(g["x"]).requires_grad_(True)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    y = F.max_pool2d(F.relu(F.conv2d(xc, sd["conv1.weight"], sd["conv1.bias"], padding=1)), 2, 2)
+    y = F.max_pool2d(F.relu(F.conv2d(y, sd["conv2.weight"], sd["conv2.bias"], padding=1)), 2, 2)
+    w_ref = [sd[k].clone().requires_grad_(True) for k in ("fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")]
+    out_ref = F.linear(F.relu(F.linear(y.flatten(1), w_ref[0], w_ref[1])), w_ref[2], w_ref[3])
+    R = torch.randn(out_ref.shape, generator=torch.Generator().manual_seed(3))
+    (out_ref * R).sum().backward()
+    xg = x.clone().requires_grad_(True)
+    fc1 = net.fc1
+    out = Fn.SimnnNetFn.apply(xg, net.conv1.weight, net.conv1.bias, net.conv2.weight, net.conv2.bias, fc1.weight,
+                              fc1.bias, net.fc2.weight, net.fc2.bias, Fn.F32)
+    (out * R.to(DEV)).sum().backward()
+    assert rel_l2(xg.grad, xc.grad) < 2e-4
+    assert rel_l2(fc1.weight.grad, w_ref[0].grad) < 2e-4 and rel_l2(net.fc2.bias.grad, w_ref[3].grad) < 2e-4
+    # the reference's shape test, feasible sizes (it draws sizes up to 32768^2: not runnable anywhere)
+    n, bs = 10, 4
+    model = SIMNN.SimNN(n).to(DEV)
+    gsz = torch.Generator().manual_seed(0)
+    for _ in range(5):
+        size = int(torch.randint(16, 200, (1,), generator=gsz).item())
+        matrix, a1, a2, a3, a4 = model(torch.randn(bs, 1, size, size, device=DEV))
+        assert matrix.size() == (bs, n, n)
+        assert all(a.size() == (bs, n) for a in (a1, a2, a3, a4))
