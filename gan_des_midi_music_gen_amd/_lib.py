@@ -4,7 +4,10 @@ import os
 import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libgdm_hip.so")
+# GDM_LIB_TAG=<tag>: load an experiment build (build.py, GDM_BUILD_TAG) instead of the shipped library; such a build
+# reports gdm_build_flavor() == 1 and bench.py refuses it.
+_TAG = os.environ.get("GDM_LIB_TAG", "")
+LIB_PATH = os.path.join(_PKG, "libgdm_hip" + (f"_{_TAG}" if _TAG else "") + ".so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3

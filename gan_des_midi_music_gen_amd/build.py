@@ -8,8 +8,11 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
-OBJ = os.path.join(CSRC, "_obj")
-LIB = os.path.join(PKG, "libgdm_hip.so")
+# GDM_BUILD_TAG=<tag> (experiments only, with GDM_HIPCC_FLAGS): objects and library of a variant build live beside the
+# shipped ones (csrc/_obj_<tag>/, libgdm_hip_<tag>.so); a process picks the variant up with GDM_LIB_TAG=<tag>.
+TAG = os.environ.get("GDM_BUILD_TAG", "")
+OBJ = os.path.join(CSRC, "_obj" + (f"_{TAG}" if TAG else ""))
+LIB = os.path.join(PKG, "libgdm_hip" + (f"_{TAG}" if TAG else "") + ".so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          # MFMA results straight into VGPRs: every kernel here post-processes its accumulators with VALU code and none

