@@ -25,6 +25,7 @@ SIGNATURES = {
     "gdm_bce_with_logits": (_I, [_P, _F, _I, _F, _P, _P, _I, _I, _P]),
     "gdm_adam_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _P]),
     "gdm_adam_step_dev": (_I, [_P, _P, _P, _P, _L, _P, _P]),
+    "gdm_adam_step_dev_pc": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P, _I, _P]),
     "gdm_stft_frames": (_I, [_P, _I, _L, _L, _I, _I, _I, _P, _P]),
     "gdm_power_spectrum": (_I, [_P, _L, _I, _I, _P, _P]),
     "gdm_power_to_db": (_I, [_P, _I, _I, _I, _F, _F, _P, _P]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "gdm_permute_pc": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
     "gdm_des_scan": (_I, [_P, _L, _I, _I, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "gdm_des_routing": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P]),
+    "gdm_piano_roll_raster": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "gdm_maxpool2_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "gdm_maxpool2_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),
 }

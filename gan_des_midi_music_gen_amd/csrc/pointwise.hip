@@ -82,6 +82,74 @@ __global__ void adam_prep_kernel(float* __restrict__ hyper) {
   hyper[7] = (float)sqrt(bc2);
 }
 
+// Adam on a parameter whose GRADIENT arrives in the channels-last ("permuted") layout and whose updated value is also
+// wanted there as a GEMM operand: model 1's fc1.weight (128, 32, P).  The weight gradient GEMM writes dW (N, P, C) in the
+// flatten order of the channels-last feature map; the parameter and its moments stay in the reference's (N, C, P) order
+// (state_dict / checkpoint compatible); the forward and dX GEMMs read a (N, P, C) copy in the activation dtype.
+// Instead of two transposing passes around Adam (gradient -> parameter order, new weight -> operand order: 235 MB of
+// HBM traffic per step) the transposes happen inside this kernel, through LDS: a workgroup owns a (128 p x 32 c) tile
+// of one row n, reads the gradient tile along c (128-byte runs), updates p/m/v along p (512-byte runs) and writes the
+// new weight back along c.
+// (the Adam arithmetic is the same expression order as adam_dev_kernel: bit-identical results)
+template <typename TS>
+__global__ __launch_bounds__(256) void adam_dev_pc_kernel(float* __restrict__ p, const float* __restrict__ g_pc,
+                                                          float* __restrict__ m, float* __restrict__ v, int C, int P,
+                                                          TS* __restrict__ shadow_pc,
+                                                          const float* __restrict__ hyper, int vec_ok) {
+  __shared__ __attribute__((aligned(16))) float tile[32][132];        // [c][p], rows 16-byte aligned
+  const float w1 = 1.0f - hyper[2], beta2 = hyper[3], omb2 = 1.0f - hyper[3], eps = hyper[4], gscale = hyper[5];
+  const float step_size = hyper[6], bc2_sqrt = hyper[7];
+  const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+  const int p0 = blockIdx.x * 128, c0 = blockIdx.y * 32, n = blockIdx.z;
+  const int64_t base = (int64_t)n * C * P;
+  const bool full = vec_ok && p0 + 128 <= P && c0 + 32 <= C;      // 16-byte accesses to p, m, v
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {                                     // gradient tile, read along c
+    const int pl = ty + 8 * i, pp = p0 + pl, c = c0 + tx;
+    tile[tx][pl] = (pp < P && c < C) ? g_pc[base + (int64_t)pp * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                                      // p, m, v along p: four elements per thread
+    const int cl = ty + 8 * i, c = c0 + cl, pp = p0 + 4 * tx;
+    const int64_t k = base + (int64_t)c * P + pp;
+    f32x4 gg = *(const f32x4*)&tile[cl][4 * tx], pv, mv, vv;
+    if (full) {
+      pv = *(const f32x4*)(p + k); mv = *(const f32x4*)(m + k); vv = *(const f32x4*)(v + k);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool ok = c < C && pp + e < P;
+        pv[e] = ok ? p[k + e] : 0.f; mv[e] = ok ? m[k + e] : 0.f; vv[e] = ok ? v[k + e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gj = gg[e] * gscale;
+      const float mj = (w1 < 0.5f) ? mv[e] + w1 * (gj - mv[e]) : gj - (gj - mv[e]) * (1.f - w1);
+      const float vj = vv[e] * beta2 + omb2 * gj * gj;
+      const float denom = sqrtf(vj) / bc2_sqrt + eps;
+      pv[e] = pv[e] - step_size * (mj / denom);
+      mv[e] = mj;
+      vv[e] = vj;
+    }
+    if (full) {
+      *(f32x4*)(p + k) = pv; *(f32x4*)(m + k) = mv; *(f32x4*)(v + k) = vv;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c < C && pp + e < P) { p[k + e] = pv[e]; m[k + e] = mv[e]; v[k + e] = vv[e]; }
+    }
+    *(f32x4*)&tile[cl][4 * tx] = pv;                                  // the elements this thread read: no hazard
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {                                     // updated weight, written along c
+    const int pl = ty + 8 * i, pp = p0 + pl, c = c0 + tx;
+    if (pp < P && c < C) shadow_pc[base + (int64_t)pp * C + c] = from_f32<TS>(tile[tx][pl]);
+  }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
@@ -391,6 +459,25 @@ extern "C" int gdm_adam_step(float* p, const float* g, float* m, float* v, int64
     hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                        1.0f - beta1, beta2, 1.0f - beta2, step_size, bc2_sqrt, eps, grad_scale);
   GDM_LAUNCH_OK("gdm_adam_step");
+  return GDM_OK;
+}
+
+extern "C" int gdm_adam_step_dev_pc(float* p, const float* g_pc, float* m, float* v, int N, int C, int P,
+                                    void* shadow_pc, int shadow_dtype, float* hyper, int advance_step, void* stream) {
+  GDM_REQUIRE(p && g_pc && m && v && shadow_pc && hyper, "gdm_adam_step_dev_pc: null pointer");
+  GDM_REQUIRE(N > 0 && C > 0 && P > 0 && N <= 65535 && (C + 31) / 32 <= 65535 && gdm_dtype_ok(shadow_dtype),
+              "gdm_adam_step_dev_pc: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (advance_step) hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(1), 0, s, hyper);
+  const dim3 grid((P + 127) / 128, (C + 31) / 32, N);
+  const int vec_ok = (P % 4 == 0) && ((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  if (shadow_dtype == GDM_BF16)
+    hipLaunchKernelGGL(adam_dev_pc_kernel<__bf16>, grid, dim3(256), 0, s, p, g_pc, m, v, C, P, (__bf16*)shadow_pc, hyper,
+                       vec_ok);
+  else
+    hipLaunchKernelGGL(adam_dev_pc_kernel<float>, grid, dim3(256), 0, s, p, g_pc, m, v, C, P, (float*)shadow_pc, hyper,
+                       vec_ok);
+  GDM_LAUNCH_OK("gdm_adam_step_dev_pc");
   return GDM_OK;
 }
 

@@ -80,18 +80,16 @@ _ws_pinned = set()        # keys that were used while a stream capture was in pr
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream); safe because every consumer is ordered on the same stream.
 
-    A captured hipGraph has the address of the buffer it saw baked in.  A buffer that was handed out during a capture
-    is therefore never released: when a later (eager) call needs more room the old buffer is retired, not freed --
-    the graph keeps writing into memory that is still ours.  Growing INSIDE a capture is refused (the allocation would
-    come from the graph's private pool and later eager launches on the same stream would share it)."""
+    A captured hipGraph has the address of the buffer it saw baked in, so a buffer that was handed out during a capture
+    is never released: when a later call (eager, or later in the same capture) needs more room, the old buffer is
+    retired -- kept alive, so the graph keeps writing into memory that is still ours -- and a larger one takes its
+    place.  (Freeing it, as the first version did, let the allocator hand the same bytes to another tensor of the
+    graph.)"""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     capturing = torch.cuda.is_current_stream_capturing()
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        if capturing and buf is not None:
-            raise GdmError(f"workspace for stream {key[1]:#x} has to grow from {buf.numel()} to {nbytes} bytes inside "
-                           "a graph capture: run the step once eagerly (same shapes) before capturing")
-        if buf is not None and key in _ws_pinned:
+        if buf is not None and (capturing or key in _ws_pinned):
             _ws_retired.append(buf)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
@@ -169,6 +167,16 @@ def adam_step_dev(p, g, m, v, hyper):
     _need_gpu(p, g, m, v, hyper)
     assert hyper.numel() == 8 and hyper.dtype == torch.float32
     _call("gdm_adam_step_dev", _p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), _stream())
+
+
+def adam_step_dev_pc(p, g_pc, m, v, n, c, pix, shadow_pc, hyper, advance_step=False):
+    """Adam on one (n, c, pix) parameter whose gradient g_pc and operand copy shadow_pc are laid out (n, pix, c)."""
+    _need_gpu(p, g_pc, m, v, shadow_pc, hyper)
+    for t in (p, g_pc, m, v):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n * c * pix, (t.shape, n, c, pix)
+    assert shadow_pc.is_contiguous() and shadow_pc.numel() == n * c * pix
+    _call("gdm_adam_step_dev_pc", _p(p), _p(g_pc), _p(m), _p(v), n, c, pix, _p(shadow_pc), gdm_dtype(shadow_pc),
+          _p(hyper), 1 if advance_step else 0, _stream())
 
 
 def bn_act_fwd(y, gamma, beta, running_mean, running_var, nbt, *, act, out_dtype=F32, training=True, momentum=0.1,
@@ -574,6 +582,17 @@ def des_routing(g, s, dim, src_mask, residue_col):
     out = torch.empty((b, dim, dim), dtype=torch.float64, device=g.device)
     _call("gdm_des_routing", _p(g), stride, b, s, dim, _p(src_mask), _p(residue_col), _p(out), _stream())
     return out
+
+
+def piano_roll_raster(row_ptr, ev_step, ev_vel, n_files, width):
+    """CSR note messages (int32 device tensors) -> (roll, dur) (n_files, 128, width) fp32."""
+    _need_gpu(row_ptr, ev_step, ev_vel)
+    assert row_ptr.dtype == torch.int32 and row_ptr.numel() == n_files * 128 + 1 and row_ptr.is_contiguous()
+    assert ev_step.dtype == torch.int32 and ev_vel.dtype == torch.int32 and ev_step.numel() == ev_vel.numel()
+    roll = torch.empty((n_files, 128, width), dtype=torch.float32, device=row_ptr.device)
+    dur = torch.empty((n_files, 128, width), dtype=torch.float32, device=row_ptr.device)
+    _call("gdm_piano_roll_raster", _p(row_ptr), _p(ev_step), _p(ev_vel), n_files, width, _p(roll), _p(dur), _stream())
+    return roll, dur
 
 
 # ---- mel-spectrogram featuriser kernels (GAN_DES/util.py:37-61) -------------------------------------------------------

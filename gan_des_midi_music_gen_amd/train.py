@@ -36,30 +36,43 @@ class FlatBuffers:
     the caller's parameter order.
     """
 
+    ALIGN = 64        # floats (256 bytes): start of the largest parameter in every flat buffer
+
     def __init__(self, params, extra=0, local=0):
         params = [p for p in params]
         assert params, "no parameters"
         dev = params[0].device     # the buffers can be laid out anywhere; the fused step itself needs a HIP device
         self.params = params
-        self.numel = sum(p.numel() for p in params)
+        self.numel = sum(p.numel() for p in params)                 # true parameter count
         big = max(range(len(params)), key=lambda i: params[i].numel())
         order = [i for i in range(len(params)) if i != big] + [big]
-        self.n_small = self.numel - params[big].numel()
+        n_small = self.numel - params[big].numel()
+        # The largest parameter starts on a 256-byte boundary in all four buffers (GEMMs write its gradient in place and
+        # take their 16-byte-vector path only for aligned operands -- a 4-byte-aligned slot sent fc1's weight-gradient
+        # GEMM down the generic kernel, 200 us instead of 25).  The gap holds zeros: Adam leaves them zero.
+        assert extra % 4 == 0 and 0 <= local <= extra
+        self.n_small = (n_small + self.ALIGN - 1) // self.ALIGN * self.ALIGN        # incl. the zero padding
+        self.n_pad = self.n_small - n_small
         self.n_extra = extra
         self.n_local = local
-        assert 0 <= local <= extra
-        self.flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
-        self.bucket = torch.zeros(extra + self.numel, dtype=torch.float32, device=dev)   # extra | small | big
+        total = self.n_small + params[big].numel()
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        # bucket: [extra | small (+ pad) | big]; the extra slots are padded so that the gradients start aligned too
+        self._lead = (extra + self.ALIGN - 1) // self.ALIGN * self.ALIGN if extra else 0
+        self._bucket_store = torch.zeros(self._lead + total, dtype=torch.float32, device=dev)
+        self.bucket = self._bucket_store[self._lead - extra:]
         self.extra = self.bucket[:extra]
         self.grad = self.bucket[extra:]
-        self.exp_avg = torch.zeros(self.numel, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self.views, self.grad_views = [None] * len(params), [None] * len(params)
         off = 0
         for i in order:
             p = params[i]
             assert p.dtype == torch.float32 and p.device == dev
             n = p.numel()
+            if i == big:
+                off = self.n_small
             v = self.flat[off:off + n].view(p.shape)
             v.copy_(p.data)
             p.data = v
@@ -95,15 +108,28 @@ class FlatBuffers:
             self._hyper_host = want
         return want
 
-    def adam(self, lr, betas, eps, grad_scale=1.0):
-        """One fused Adam launch over the flat buffer.  Step counter and hyper-parameters live in an 8-float device
-        record (so a captured hipGraph replays correctly); the host only rewrites it when lr/scale change."""
+    def adam(self, lr, betas, eps, grad_scale=1.0, big_pc=None):
+        """One fused Adam step over the flat buffer.  Step counter and hyper-parameters live in an 8-float device
+        record (so a captured hipGraph replays correctly); the host only rewrites it when lr/scale change.
+
+        big_pc = (n, c, pix, shadow): the largest parameter is an (n, c, pix) tensor whose gradient slot holds the
+        (n, pix, c) "channels-last" layout its weight-gradient GEMM produces, and ``shadow`` (n, pix, c) receives the
+        updated value as the GEMM operand copy (model 1's fc1.weight): the small parameters take the plain kernel, the
+        big one the transposing kernel -- no separate permute passes."""
         want = self.sync_hyper(lr, betas, eps, grad_scale)
         if self._hyper is None:
             self._hyper = ops.adam_hyper(self.flat.device, *want, step=self.step_count)
             self._hyper_host = want
         self.step_count += 1
-        ops.adam_step_dev(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self._hyper)
+        if big_pc is None:
+            ops.adam_step_dev(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self._hyper)
+            return
+        ns = self.n_small
+        n, c, pix, shadow = big_pc
+        assert n * c * pix == self.flat.numel() - ns and ns > 0
+        ops.adam_step_dev(self.flat[:ns], self.grad[:ns], self.exp_avg[:ns], self.exp_avg_sq[:ns], self._hyper)
+        ops.adam_step_dev_pc(self.flat[ns:], self.grad[ns:], self.exp_avg[ns:], self.exp_avg_sq[ns:], n, c, pix, shadow,
+                             self._hyper, advance_step=False)
 
 
 class _TrainerBase:
@@ -125,17 +151,25 @@ class _TrainerBase:
         """Start the SUM all-reduce of the largest gradient (call on the stream that produced it); no-op on 1 rank."""
         self._pending = dp.allreduce_async_(self.d.bucket_big(), self.pg)
 
-    def _reduce_and_step(self):
-        # head of the bucket = [disc_loss | small gradients]: SUM here, 1/world folded into Adam (and the loss read-out)
+    def _reduce(self):
+        """The data-parallel exchange of everything that is not yet in flight: SUM over ranks (1/world is folded into
+        Adam and into the loss read-out).  No-op on one rank."""
         pending = getattr(self, "_pending", None)
         if pending is None:
             red = self.d.bucket_reduced()
             dp.allreduce_bucket_(red, red.numel(), self.pg)                         # everything in one collective
         else:
+            # head of the bucket = [disc_loss | small gradients]; the big tail has been in flight since its GEMM finished
             dp.allreduce_bucket_(self.d.bucket_head(), self.d.bucket_head().numel(), self.pg)
             pending.wait()                                                          # current stream waits for the tail
             self._pending = None
+
+    def _adam(self):
         self.d.adam(self.lr, self.betas, self.eps, grad_scale=1.0 / self.world)
+
+    def _reduce_and_step(self):
+        self._reduce()
+        self._adam()
 
     def _sync_hyper(self):
         self.d.sync_hyper(self.lr, self.betas, self.eps, 1.0 / self.world)
@@ -208,17 +242,25 @@ class SimnnTrainer(_TrainerBase):
         self._scratch_grads = None
         self._pending_fake = None  # step_pipelined: fake batch whose generator half has not run yet (= _fake_buf)
         self._fake_buf = None      # trainer-owned copy of that batch
-        self._prepared_stale = False
 
     def invalidate_weights(self):
         """Call after changing discriminator weights from outside (e.g. load_state_dict)."""
         self._prepared = None
-        self._prepared_stale = False
 
     def _refresh_operands(self):
         if self._prepared is not None:
             Fn.simnn_disc_prepare(self.d.views[2], self.d.views[4], self.dt, out=self._prepared)
-            self._prepared_stale = False
+
+    def _adam(self):
+        """Adam, with fc1.weight's two layout changes folded in: its gradient slot holds the channels-last (128, P, 32)
+        layout the weight-gradient GEMM writes (``disc.fc1.weight.grad`` is therefore NOT in the parameter's order while
+        a trainer owns the module), and the kernel writes the updated weight's operand copy ``self._prepared[1]`` itself;
+        conv2's packed images are rebuilt right after."""
+        wf1 = self.d.views[4]
+        n, k = wf1.shape
+        self.d.adam(self.lr, self.betas, self.eps, grad_scale=1.0 / self.world,
+                    big_pc=(n, 32, k // 32, self._prepared[1]))
+        ops.simnn_conv2_pack(self.d.views[2], self.dt, out=self._prepared[0])
 
     def _gen_state(self):
         g = self.gen
@@ -242,13 +284,12 @@ class SimnnTrainer(_TrainerBase):
         n, k = wf1p.shape
         main = torch.cuda.current_stream()
         side = self._streams(p1.device) if (self.overlap and fork) else None
-        # branch A: fc1 weight gradient (GEMM + permute back to the parameter's flatten order)
+        # branch A: fc1 weight gradient
         if side:
             side[1].wait_stream(main)
         with torch.cuda.stream(side[1] if side else main):
-            dwf1p = ops.gemm(dh.t(), flat, compute=dt)
-            ops.permute_pc(dwf1p, n, k // 32, 32, out=outs[4])
-            keep.append(dwf1p)
+            # (128, P*32): the channels-last layout of the feature map, kept as it is -- Adam transposes on the fly
+            ops.gemm(dh.t(), flat, compute=dt, out=outs[4].view(n, k))
             if self.world > 1 and outs is self.d.grad_views:
                 # 99.9 % of the exchange (fc1.weight's gradient) starts now and overlaps the convolution backward
                 self._reduce_big_async()
@@ -284,9 +325,6 @@ class SimnnTrainer(_TrainerBase):
         side = self._streams(real.device) if self.overlap else None
         keep = []
         ws, bns = self._gen_state()
-        if self._prepared is not None and self._prepared_stale:
-            Fn.simnn_disc_prepare(w2, wf1, dt, out=self._prepared)
-            self._prepared_stale = False
 
         def generator_forward():
             # SIMNN.py:293-296; the output only feeds the (external) bridge -> own stream
@@ -325,21 +363,13 @@ class SimnnTrainer(_TrainerBase):
         # fc2 + sigmoid + both BCE terms (labels 0.9 / 0.1, SIMNN.py:284-311) + head backward: one launch pair
         _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 0.9, 0.1, loss_out=self.loss_d, grad_out=(gv[6], gv[7], gv[5]))
         self._d_backward(saved, dh, pack, wf1p, gv, (real, fake), keep)
+        # Adam also rewrites the weight-derived operands in place (fc1's operand copy inside the kernel, conv2's packed
+        # images right after): they are cross-iteration state, so their storage must be stable under graph replay
         self._reduce_and_step()
-        # weights changed: rebuild the packed conv2 images and the permuted fc1 operand once, use them for the G-step
-        # forward below AND for the next iteration's D-step forward
-        # (refreshed in place: they are cross-iteration state, so their storage must be stable under graph replay)
-        # -- on a side stream: conv1 of the G-step forward does not read them, so the 50 MB permute/cast pass runs beside it
-        if side:
-            side[1].wait_stream(main)
-        with torch.cuda.stream(side[1] if side else main):
-            Fn.simnn_disc_prepare(w2, wf1, dt, out=self._prepared)
         # --- "generator" step (SIMNN.py:322-331): D forward on fake with the updated weights, label 1.0
         p1g = torch.empty((b, h1, w1s, 16), dtype=adt, device=real.device)
         code1g = torch.empty((b, h1, w1s), dtype=torch.int64, device=real.device)
         ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1g, code1g))
-        if side:
-            main.wait_stream(side[1])
         hid_g, saved_g = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1g, code1g))
         _prob, dh_g, _ = ops.simnn_head(hid_g, wf2, bf2, b, 1.0, 1.0, loss_out=self.loss_g, want_grad=not self.elide)
         if not self.elide:
@@ -392,7 +422,6 @@ class SimnnTrainer(_TrainerBase):
         pending = self._pending_fake
         if self._prepared is None:
             self._prepared = Fn.simnn_disc_prepare(w2, wf1, dt)
-            self._prepared_stale = False
         pack, wf1p = self._prepared
         if self._scratch_grads is None:
             self._scratch_grads = [torch.empty_like(g) for g in gv]
@@ -408,18 +437,7 @@ class SimnnTrainer(_TrainerBase):
             generated, gsaved = Fn.simnn_gen_forward(noise, ws, bns, self.gen.training, dt, cache=self._tm_cache)
             keep.append(gsaved)
         self.last_generated = generated
-        if self._prepared_stale:
-            # weights changed in the previous call: rebuild the packed conv2 images / permuted fc1 operand beside conv1
-            if side:
-                side[1].wait_stream(main)
-            with torch.cuda.stream(side[1] if side else main):
-                Fn.simnn_disc_prepare(w2, wf1, dt, out=self._prepared)
-            self._prepared_stale = False
-            ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
-            if side:
-                main.wait_stream(side[1])
-        else:
-            ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
+        ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
         # generator half of the previous iteration: reads the weights / prepared operands that stay untouched until
         # this call's Adam, writes only gen_loss and scratch buffers.  Then, on the same stream (so after the half's last
         # read of it), the trainer's own copy of the fake batch is refreshed with THIS iteration's: the caller may
@@ -439,8 +457,7 @@ class SimnnTrainer(_TrainerBase):
         self._d_backward(saved, dh, pack, wf1p, gv, (real, fake), keep)
         if side:
             main.wait_stream(side[2])
-        self._reduce_and_step()
-        self._prepared_stale = True
+        self._reduce_and_step()         # (Adam refreshes the weight-derived operands in place)
         if side:
             main.wait_stream(side[0])
         self._pending_fake = self._fake_buf
@@ -453,10 +470,6 @@ class SimnnTrainer(_TrainerBase):
         """Run the generator half left pending by ``step_pipelined``; returns its gen_loss (device tensor)."""
         if self._pending_fake is None:
             return self.loss_g
-        w1, b1, w2, b2, wf1 = self.d.views[:5]
-        if self._prepared_stale:
-            Fn.simnn_disc_prepare(w2, wf1, self.dt, out=self._prepared)
-            self._prepared_stale = False
         keep = []
         self._generator_half(self._pending_fake, keep)
         self._pending_fake = None
@@ -548,7 +561,25 @@ class MmganTrainer(_TrainerBase):
     @torch.no_grad()
     def step(self, piano_roll, durations, beats, noise1, noise2, fake_a, fake_b, g1_in_a=None, g1_in_b=None):
         """fake_a / fake_b: (B,2,128,T) tensors or callables ``f(g1_out, g2_out) -> tensor`` standing in for the
-        DES bridge of the D-step and G-step forwards (network_tests.py:294, 312)."""
+        DES bridge of the D-step and G-step forwards (network_tests.py:294, 312).
+
+        The iteration is three pieces -- everything up to the gradient (``_part_a``), the data-parallel exchange, Adam and
+        the generator step (``_part_b``) -- so that with more than one rank the two compute pieces can be replayed as
+        hipGraphs around the eager collective (``capture`` / ``replay``)."""
+        self._part_a(piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a)
+        self._reduce()
+        self._part_b(piano_roll, beats, noise1, noise2, fake_b, g1_in_b)
+        self.iterations += 1
+        return self.loss_d, self.loss_g
+
+    def _sides(self, dev):
+        if self._gen_stream is None:
+            self._gen_stream = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        return self._gen_stream
+
+    def _part_a(self, piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a):
+        """D step up to the gradient (network_tests.py:293-307): generators' first forward on side streams beside the
+        discriminator's forward + loss + backward; every branch is joined before returning."""
         dt = self.dt
         w1, b1, w2, b2, wf, bf = self.d.views
         gv = self.d.grad_views
@@ -559,13 +590,10 @@ class MmganTrainer(_TrainerBase):
         # the generators only feed the (external) bridge: each runs on a side stream of its own beside the
         # discriminator kernels (a generator's second forward follows its first one: BN running statistics)
         main = torch.cuda.current_stream()
-        if self._gen_stream is None:
-            self._gen_stream = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
-        sides = self._gen_stream
+        sides = self._sides(dev)
         # (a branch forked at the very root of a captured graph was observed to run before, not beside, the main
         # branch: fork after a first small launch on the main stream)
         self.d.extra[1:4].zero_()
-        # --- D step (network_tests.py:293-308)
         for sd in sides:
             sd.wait_stream(main)
         g1, g2 = self._generators_forward(noise1, noise2, beats, g1_in_a, sides)
@@ -595,10 +623,24 @@ class MmganTrainer(_TrainerBase):
             grads = Fn.dcnn_backward(saved, dl, w2, wf, dt)[:6]
             for gview, g in zip(gv, grads):
                 gview.copy_(g.view(gview.shape))
-        self._reduce_and_step()
+        for sd in sides:
+            main.wait_stream(sd)
+
+    def _part_b(self, piano_roll, beats, noise1, noise2, fake_b, g1_in_b):
+        """Adam (308), then the "G" step (311-315): both generators run again (2nd BN statistics update), D forward on
+        the new fake (+ the dead backward in faithful mode)."""
+        dt = self.dt
+        w1, b1, w2, b2, wf, bf = self.d.views
+        gv = self.d.grad_views
+        t = piano_roll.shape[2]
+        fused = self._fused_ok(t)
+        main = torch.cuda.current_stream()
+        sides = self._sides(piano_roll.device)
+        self._adam()
         if fused:
             ops.dcnn_pack(w1, b1, w2, b2, wf, bf, t, out=self._pack)     # weights changed: refresh in place
-        # --- "G" step (311-315): both generators run again (2nd BN statistics update), D forward on the new fake
+        for sd in sides:
+            sd.wait_stream(main)
         g1b, g2b = self._generators_forward(noise1, noise2, beats, g1_in_b, sides)
         if callable(fake_b):
             for sd in sides:
@@ -621,17 +663,20 @@ class MmganTrainer(_TrainerBase):
                 Fn.dcnn_backward(saved_g, dlg, w2, wf, dt)     # dead values (only D's .grad in the reference)
         for sd in sides:
             main.wait_stream(sd)
-        self.iterations += 1
-        return self.loss_d, self.loss_g
 
     # ---- hipGraph capture for fixed input buffers --------------------------------------------------------------------
     def capture(self, piano_roll, durations, beats, noise1, noise2, fake_a, fake_b, g1_in_a, g1_in_b):
-        """Record one iteration on fixed tensors into a hipGraph (the iteration is ~130 small launches: replay removes
-        the host launch cost).  Needs tensor bridge outputs, explicit generator-1 inputs (the reference draws them on
-        the CPU generator, network_tests.py:83-84, which cannot be part of a device graph) and a single rank."""
+        """Record one iteration on fixed tensors (the iteration is ~130 small launches: replay removes the host launch
+        cost).  Needs tensor bridge outputs and explicit generator-1 inputs (the reference draws them on the CPU
+        generator, network_tests.py:83-84, which cannot be part of a device graph).
+
+        One rank: the whole iteration is ONE hipGraph.  More ranks: TWO graphs -- everything up to the gradient, and
+        Adam + the generator step -- with the gradient all-reduce issued eagerly between them (a collective is not
+        part of a graph here), so a data-parallel rank replays 2 graphs + 1 collective per iteration instead of ~130
+        eager launches."""
         args = (piano_roll, durations, beats, noise1, noise2, fake_a, fake_b, g1_in_a, g1_in_b)
-        if any(callable(a) for a in args) or any(a is None for a in args) or self.world > 1:
-            raise ops.GdmError("graph capture needs tensor inputs (incl. g1_in_a/g1_in_b) and a single rank")
+        if any(callable(a) for a in args) or any(a is None for a in args):
+            raise ops.GdmError("graph capture needs tensor inputs (incl. g1_in_a/g1_in_b)")
         self._static = args
         warm = torch.cuda.Stream(piano_roll.device)
         warm.wait_stream(torch.cuda.current_stream())
@@ -640,16 +685,30 @@ class MmganTrainer(_TrainerBase):
                 self.step(*args[:7], g1_in_a=g1_in_a, g1_in_b=g1_in_b)
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self.step(*args[:7], g1_in_a=g1_in_a, g1_in_b=g1_in_b)
+        if self.world == 1:
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self.step(*args[:7], g1_in_a=g1_in_a, g1_in_b=g1_in_b)
+            self.iterations -= 1
+        else:
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self._part_a(piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a)
+            pool = ga.pool()
+            with torch.cuda.graph(gb, pool=pool):
+                self._part_b(piano_roll, beats, noise1, noise2, fake_b, g1_in_b)
+            self._graph = (ga, gb)
         self.d.step_count -= 1     # the captured call did not execute: the device-side step counter did not move
-        self.iterations -= 1
         return self._graph
 
     def replay(self):
         self._sync_hyper()         # lr schedule etc.: the captured Adam reads the device record
-        self._graph.replay()
+        if isinstance(self._graph, tuple):
+            self._graph[0].replay()
+            self._reduce()
+            self._graph[1].replay()
+        else:
+            self._graph.replay()
         self.d.step_count += 1
         self.iterations += 1
         return self.loss_d, self.loss_g

@@ -67,6 +67,14 @@ int gdm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, int s
  * be replayed: hyper = 8 floats {step (int32 bits), lr, beta1, beta2, eps, grad_scale, -, -}; every call increments
  * the step and recomputes the bias corrections on the device (in double), then updates the flat range.             */
 int gdm_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float* hyper, void* stream);
+/* The same update for ONE parameter viewed as (N, C, P) whose gradient g_pc is laid out (N, P, C) -- model 1's
+ * fc1.weight (128, 32, H2*W2): its weight-gradient GEMM produces the channels-last flatten order -- and whose updated
+ * value is also written to shadow_pc (N, P, C) in shadow_dtype, the operand copy the forward / dX GEMMs read.  p, m, v
+ * keep the reference's (N, C, P) order.  Replaces two gdm_permute_pc passes around the optimizer.  advance_step: 1 =
+ * increment the step and recompute the bias corrections first (like gdm_adam_step_dev); 0 = use the record as it is
+ * (a second range of the same optimizer step).                                                                      */
+int gdm_adam_step_dev_pc(float* p, const float* g_pc, float* m, float* v, int N, int C, int P, void* shadow_pc,
+                         int shadow_dtype, float* hyper, int advance_step, void* stream);
 
 /* ---- batch norm, training mode, rows x channels matrices (aten::native_batch_norm + activation) ----------------
  * y: (rows, channels) fp32 pre-norm values (row-major).  Computes per-channel batch mean / biased variance with a
@@ -231,6 +239,14 @@ int gdm_des_scan(const float* g, int64_t sample_stride, int B, int S, int dim, f
                  uint64_t* zero_mask, float* aux_or_null, int32_t* flags, void* stream);
 int gdm_des_routing(const float* g, int64_t sample_stride, int B, int S, int dim, const uint8_t* src_mask,
                     const int32_t* residue_col, double* out, void* stream);
+
+/* ---- piano-roll rasteriser (the scatter of generate_piano_roll, MMGAN_MIDI_DES/datasets.py:29-45), batched over files.
+ * Messages of row r = file * 128 + note are ev_*[row_ptr[r] .. row_ptr[r+1]) in file order; ev_step = one-second time
+ * step of the message, ev_vel = velocity of a note_on (0..127) or -1 for a note_off.  Writes roll, dur (n_files,128,W)
+ * fp32: roll[note][step] = last note_on velocity, dur[note][on:off] = off - on of the note_off that closed it.
+ * The host has already cut each file's list where the reference's loop stops.                                        */
+int gdm_piano_roll_raster(const int32_t* row_ptr, const int32_t* ev_step, const int32_t* ev_vel, int n_files, int W,
+                          float* roll, float* dur, void* stream);
 
 /* ---- mel-spectrogram featuriser (GAN_DES/util.py:37-61: torchaudio MelSpectrogram + AmplitudeToDB) --------------
  * The producer of model 1's discriminator input.  DFT and mel filter bank are gdm_gemm calls in exact fp32 (window

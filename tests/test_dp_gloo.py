@@ -87,12 +87,18 @@ def test_flat_buffers_views_alias_parameters_and_grads():
     disc = osn.Discriminator(input_hw=HW)
     before = [p.detach().clone() for p in disc.parameters()]
     fb = FlatBuffers(list(disc.parameters()), extra=8, local=4)
-    assert fb.numel == sum(p.numel() for p in disc.parameters()) and fb.bucket.numel() == fb.numel + 8
+    assert fb.numel == sum(p.numel() for p in disc.parameters())
+    assert fb.bucket.numel() == fb.numel + fb.n_pad + 8 and fb.n_small % 64 == 0 and 0 <= fb.n_pad < 64
     params = list(disc.parameters())
     big = max(range(len(params)), key=lambda i: params[i].numel())
     off = 0
-    for i in [j for j in range(len(params)) if j != big] + [big]:        # physical order: small ..., largest last
+    for i in [j for j in range(len(params)) if j != big] + [big]:        # physical order: small ..., pad, largest last
         p = params[i]
+        if i == big:
+            off = fb.n_small
+            # aligned GEMM / Adam operand (relative to the allocation, which the device allocator aligns to 512 bytes)
+            assert (p.data_ptr() - fb.flat.data_ptr()) % 256 == 0
+            assert (p.grad.data_ptr() - fb._bucket_store.data_ptr()) % 256 == 0
         assert torch.equal(p.detach(), before[i])
         assert p.data_ptr() == fb.flat.data_ptr() + 4 * off and p.grad.data_ptr() == fb.grad.data_ptr() + 4 * off
         assert fb.views[i].data_ptr() == p.data_ptr() and fb.grad_views[i].data_ptr() == p.grad.data_ptr()

@@ -57,6 +57,27 @@ for it in range(2):
 torch.cuda.synchronize()
 out["mmgan"] = {"d_loss": mt.disc_loss_value(), "g_loss": mt.gen_loss_global(), "fc": mm.discriminator.fc.weight.detach().cpu(),
                 "c2": mm.discriminator.conv2.weight.detach().cpu()}
+# model 2 on the benchmarked path (bf16, fused kernels): eager steps vs the replayed graph(s) -- with 2 ranks that is two
+# hipGraphs around the eager gradient all-reduce
+d = synthetic.mmgan_inputs(GB, 50, seed=960, device=dev)
+sh = {k: v[lo:hi].contiguous() for k, v in d.items()}
+keys = ("piano_roll", "durations", "beats", "noise1", "noise2", "fake_a", "fake_b", "g1_in_a", "g1_in_b")
+for kind in ("eager", "graph"):
+    torch.manual_seed(0)
+    mm = NT.MultiModalGAN(z_dim=50, adj_size=(64, 64), roll_size=(2, 128, 50), input_dim=50, output_dim=20, device=dev)
+    mt = MmganTrainer(mm, compute_dtype="bf16")
+    if kind == "graph":
+        g = mt.capture(*[sh[k] for k in keys])              # two eager iterations inside
+        assert isinstance(g, tuple) == (world > 1)
+        for _ in range(2):
+            mt.replay()
+    else:
+        for _ in range(4):
+            mt.step(*[sh[k] for k in keys[:7]], g1_in_a=sh["g1_in_a"], g1_in_b=sh["g1_in_b"])
+    torch.cuda.synchronize()
+    out["mmgan_bf16_" + kind] = {"d_loss": mt.disc_loss_value(), "g_loss": mt.gen_loss_global(),
+                                 "fc": mm.discriminator.fc.weight.detach().cpu(),
+                                 "c1": mm.discriminator.conv1.weight.detach().cpu()}
 if rank == 0:
     torch.save(out, os.environ["GDM_OUT"])
 if world > 1:
@@ -94,6 +115,11 @@ def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path):
     # the pipelined schedule is the same arithmetic: identical to the sequential one within a run
     for k in ("fc1", "c1", "fc2b"):
         assert torch.equal(one["simnn"][k], one["simnn_pipelined"][k]), k
+    # graph replay (one graph on one rank, two graphs around the eager all-reduce on two) == eager steps, bit for bit
+    for run in (one, two):
+        e, g = run["mmgan_bf16_eager"], run["mmgan_bf16_graph"]
+        assert e["d_loss"] == g["d_loss"] and e["g_loss"] == g["g_loss"], (e["d_loss"], g["d_loss"])
+        assert torch.equal(e["fc"], g["fc"]) and torch.equal(e["c1"], g["c1"])
     for model in ("simnn", "simnn_pipelined", "mmgan"):
         a, b = one[model], two[model]
         assert abs(a["d_loss"] - b["d_loss"]) < 1e-5 * max(1.0, abs(a["d_loss"])), (model, a["d_loss"], b["d_loss"])

@@ -187,6 +187,41 @@ def test_adam_matches_torch_optim():
             assert upd_err <= 6e-7 + 1e-4 * lr * step, f"adam step {step}: update err {upd_err:.3e}"
 
 
+@pytest.mark.parametrize("n,c,pix,sdt", [(128, 32, 2048, torch.bfloat16), (3, 32, 100, torch.float32),
+                                         (2, 20, 37, torch.bfloat16), (5, 32, 128, torch.bfloat16)])
+def test_adam_with_permuted_gradient_and_operand_copy(n, c, pix, sdt):
+    """gdm_adam_step_dev_pc == gdm_adam_step_dev on the un-permuted gradient, bit for bit, and the operand copy it
+    writes is the updated parameter transposed to (n, pix, c) in the copy's dtype (model 1's fc1.weight)."""
+    g = torch.Generator().manual_seed(n * pix + c)
+    p0 = torch.randn(n, c, pix, generator=g).to(DEV)
+    p_a, p_b = p0.clone(), p0.clone()
+    m_a, v_a = torch.zeros_like(p0), torch.zeros_like(p0)
+    m_b, v_b = torch.zeros_like(p0), torch.zeros_like(p0)
+    shadow = torch.empty((n, pix, c), dtype=sdt, device=DEV)
+    h_a = ops.adam_hyper(torch.device(DEV), 2e-5, 0.5, 0.999, 1e-8, 0.5)
+    h_b = ops.adam_hyper(torch.device(DEV), 2e-5, 0.5, 0.999, 1e-8, 0.5)
+    for step in range(3):
+        g_pc = (torch.randn(n, pix, c, generator=g) * 10.0 ** (-step)).to(DEV)
+        ops.adam_step_dev(p_a.view(-1), g_pc.permute(0, 2, 1).contiguous().view(-1), m_a.view(-1), v_a.view(-1), h_a)
+        ops.adam_step_dev_pc(p_b.view(-1), g_pc.view(-1), m_b.view(-1), v_b.view(-1), n, c, pix, shadow, h_b,
+                             advance_step=True)
+        assert torch.equal(p_a, p_b) and torch.equal(m_a, m_b) and torch.equal(v_a, v_b), step
+        assert torch.equal(shadow, p_b.permute(0, 2, 1).contiguous().to(sdt)), step
+    assert torch.equal(h_a, h_b)
+    # a misaligned parameter slot takes the scalar path: same result
+    buf = torch.zeros(n * c * pix + 1, device=DEV)
+    pu = buf[1:]
+    pu.copy_(p0.view(-1))
+    mu, vu = torch.zeros(n * c * pix + 1, device=DEV)[1:], torch.zeros(n * c * pix + 1, device=DEV)[1:]
+    h_u = ops.adam_hyper(torch.device(DEV), 2e-5, 0.5, 0.999, 1e-8, 0.5)
+    g_pc = torch.randn(n, pix, c, generator=torch.Generator().manual_seed(1)).to(DEV)
+    ops.adam_step_dev_pc(pu, g_pc.view(-1), mu, vu, n, c, pix, shadow, h_u, advance_step=True)
+    p_c, m_c, v_c = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    h_c = ops.adam_hyper(torch.device(DEV), 2e-5, 0.5, 0.999, 1e-8, 0.5)
+    ops.adam_step_dev(p_c.view(-1), g_pc.permute(0, 2, 1).contiguous().view(-1), m_c.view(-1), v_c.view(-1), h_c)
+    assert torch.equal(pu, p_c.view(-1))
+
+
 @pytest.mark.parametrize("rows,c,act", [(16, 256, ACT_SIGMOID), (4, 4096, ACT_SIGMOID), (256, 20, ACT_SIGMOID),
                                         (16 * 64, 64, ACT_RELU), (5000, 32, ACT_RELU), (65536, 32, ACT_RELU),
                                         (4096, 128, ACT_RELU), (777, 8, ACT_RELU)])
