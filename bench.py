@@ -149,7 +149,7 @@ def build_simnn(args, rank, dev):
         step = tr.replay
     elif pipelined:
         eager()        # every timed call must find a pending generator half, like every later one
-    return tr, step, eager_sequential
+    return tr, step, eager_sequential, eager
 
 
 def build_mmgan(args, rank, dev):
@@ -171,7 +171,7 @@ def build_mmgan(args, rank, dev):
         tr.capture(d["piano_roll"], d["durations"], d["beats"], d["noise1"], d["noise2"], d["fake_a"], d["fake_b"],
                    d["g1_in_a"], d["g1_in_b"])
         step = tr.replay
-    return tr, step, eager
+    return tr, step, eager, eager
 
 
 def host_cores():
@@ -244,7 +244,7 @@ def main():
         raise SystemExit("libgdm_hip.so was built with experiment switches (GDM_HIPCC_FLAGS): rebuild with the shipped "
                          "flags (`python -m gan_des_midi_music_gen_amd.build`) before benchmarking")
 
-    tr, step, eager_step = (build_simnn if args.workload == "simnn" else build_mmgan)(args, rank, dev)
+    tr, step, eager_step, step_eager_same_schedule = (build_simnn if args.workload == "simnn" else build_mmgan)(args, rank, dev)
 
     def barrier():
         if world > 1:
@@ -270,12 +270,25 @@ def main():
     roofline = None
     if not args.no_roofline:
         dk = dominant_kernel(args.workload, args.dtype, (128, args.width), args.seq)
-        ops.time_entry_point(dk["name"])     # event pairs need eager launches (a replayed graph has no host calls)
-        for _ in range(args.steps):
-            eager_step()
-        torch.cuda.synchronize()
-        avg_ms, launches = ops.timed_durations_ms()
-        ops.time_entry_point(None)
+
+        def time_kernel(fn):
+            """K more iterations, eagerly (a replayed graph has no host calls to bracket), with every launch of the
+            dominant kernel between two HIP events recorded on the stream it is launched on."""
+            ops.time_entry_point(dk["name"])
+            for _ in range(args.steps):
+                fn()
+            torch.cuda.synchronize()
+            res = ops.timed_durations_ms()
+            ops.time_entry_point(None)
+            return res
+        # (a) alone: the halves of an iteration one after the other, so the kernel has the chip to itself; (b) in the
+        # schedule that was timed above (model 1: pipelined, the other chain runs beside it and the launch is
+        # time-shared).  `frac` is taken on the SLOWER of the two.
+        alone_ms, launches = time_kernel(eager_step)
+        sched_ms, _ = time_kernel(step_eager_same_schedule) if step_eager_same_schedule is not eager_step else (alone_ms, 0)
+        avg_ms = max(alone_ms, sched_ms)
+        if hasattr(tr, "flush"):
+            tr.flush()
         if args.workload == "simnn":
             # the timed entry point runs on the 2B batch (D step) and, in faithful mode, on B (the dead backward)
             samples_per_launch = 2.0 * args.batch if args.mode == "elided" else 1.5 * args.batch
@@ -283,7 +296,8 @@ def main():
             roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dk["kernel"],
                         "algorithmic_bytes_per_launch": int(dk["bytes_per_sample"] * samples_per_launch),
-                        "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
+                        "avg_launch_ms": round(avg_ms, 4), "avg_launch_ms_alone": round(alone_ms, 4),
+                        "avg_launch_ms_in_timed_schedule": round(sched_ms, 4), "launches_timed": launches}
         else:
             # the timed entry point runs on the 2B batch (D step) and on B (the generator step's pass through D)
             samples_per_launch = 1.5 * args.batch
@@ -291,11 +305,13 @@ def main():
             roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tflops / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None, "kernel": dk["kernel"],
                         "algorithmic_flops_per_launch": int(dk["flops_per_sample"] * samples_per_launch),
-                        "avg_launch_ms": round(avg_ms, 4), "launches_timed": launches}
+                        "avg_launch_ms": round(avg_ms, 4), "avg_launch_ms_alone": round(alone_ms, 4),
+                        "avg_launch_ms_in_timed_schedule": round(sched_ms, 4), "launches_timed": launches}
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if roofline and os.path.exists(tfile):
-            try:
-                roofline["traffic"] = json.load(open(tfile)).get(f"{args.workload}_{args.dtype}")
+            try:     # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.sh): a
+                roofline["traffic"] = json.load(open(tfile)).get(f"{args.workload}_{args.dtype}")     # separate run
+                roofline["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc, separate passes, same command)"
             except Exception:
                 pass
     barrier()

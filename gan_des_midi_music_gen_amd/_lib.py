@@ -52,7 +52,8 @@ SIGNATURES = {
     "gdm_simnn_head_workspace_bytes": (_Z, [_I]),
     "gdm_simnn_head": (_I, [_P, _P, _P, _I, _I, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "gdm_linear_bn_act_max_rows": (_I, []),
-    "gdm_linear_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "gdm_linear_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I,
+                                   _P]),
     "gdm_dcnn_fused_supported": (_I, [_I]),
     "gdm_dcnn_pack_bytes": (_Z, [_I]),
     "gdm_dcnn_pack": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P]),

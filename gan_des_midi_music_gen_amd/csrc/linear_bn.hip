@@ -16,7 +16,7 @@ namespace {
 constexpr int LB_M = 256, LB_N = 32, LB_KT = 32, LB_LD = LB_KT + 8;
 
 template <bool VEC>
-__global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* x, const float* __restrict__ w,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
@@ -24,16 +24,31 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restr
                                                             float* __restrict__ running_var,
                                                             int64_t* __restrict__ nbt, float momentum, float eps,
                                                             int act, int training, int M, int N, int K,
-                                                            float* __restrict__ y_out, float* __restrict__ out,
+                                                            float* y_out, float* out,
                                                             float* __restrict__ save_mean,
-                                                            float* __restrict__ save_invstd) {
+                                                            float* __restrict__ save_invstd, int groups,
+                                                            int stat_repeats) {
   __shared__ __attribute__((aligned(16))) __bf16 As[2][LB_M * LB_LD];     // [hi | lo]
   __shared__ __attribute__((aligned(16))) __bf16 Bs[2][LB_N * LB_LD];
   __shared__ float colred[4][LB_N];
   __shared__ float colstat[2][LB_N];
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
   const int n0 = blockIdx.x * LB_N;
-  if (blockIdx.x == 0 && t == 0 && training && nbt) nbt[0] += 1;
+  if (blockIdx.x == 0 && t == 0 && training && nbt) nbt[0] += (int64_t)groups * stat_repeats;
+  // `groups` independent batches of M rows share the weights and are normalised with their OWN batch statistics, one
+  // after the other (a generator's two forwards of one training iteration, network_tests.py:294 and 312, in one launch:
+  // the running statistics take the updates in that order); `stat_repeats` applies a group's running-statistics update
+  // that many times (the second forward of the beat generator sees exactly the first one's inputs).
+  const float* const x_all = x;
+  float* const out_all = out;
+  float* const y_all = y_out;
+  for (int grp = 0; grp < groups; ++grp) {
+  x = x_all + (int64_t)grp * M * K;
+  out = out_all + (int64_t)grp * M * N;
+  y_out = y_all ? y_all + (int64_t)grp * M * N : nullptr;
+  float* const save_mean_g = save_mean + (int64_t)grp * N;
+  float* const save_invstd_g = save_invstd + (int64_t)grp * N;
+  __syncthreads();                          // the previous group's LDS reads are done
 
   f32x4 acc[4][2];
 #pragma unroll
@@ -162,11 +177,16 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restr
       colstat[1][t] = 1.0f / sqrtf(var_b + eps);
       const int n = n0 + t;
       if (n < N) {
-        save_mean[n] = colstat[0][t];
-        save_invstd[n] = colstat[1][t];
+        save_mean_g[n] = colstat[0][t];
+        save_invstd_g[n] = colstat[1][t];
         if (running_mean) {
-          running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * colstat[0][t];
-          running_var[n] = (1.f - momentum) * running_var[n] + momentum * (m2 / (float)max(M - 1, 1));
+          float rm = running_mean[n], rv = running_var[n];
+          for (int rep = 0; rep < stat_repeats; ++rep) {
+            rm = (1.f - momentum) * rm + momentum * colstat[0][t];
+            rv = (1.f - momentum) * rv + momentum * (m2 / (float)max(M - 1, 1));
+          }
+          running_mean[n] = rm;
+          running_var[n] = rv;
         }
       }
     }
@@ -179,7 +199,7 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restr
       const int n = n0 + 16 * j + lr;
       mean[j] = n < N ? running_mean[n] : 0.f;
       invstd[j] = n < N ? 1.0f / sqrtf(running_var[n] + eps) : 0.f;
-      if (n < N && lg == 0 && wv == 0) { save_mean[n] = mean[j]; save_invstd[n] = invstd[j]; }
+      if (n < N && lg == 0 && wv == 0) { save_mean_g[n] = mean[j]; save_invstd_g[n] = invstd[j]; }
     }
   }
 #pragma unroll
@@ -213,6 +233,7 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* __restr
         }
       }
   }
+  }   // groups
 }
 
 }  // namespace
@@ -223,8 +244,9 @@ extern "C" int gdm_linear_bn_act_fwd(const float* x, const float* w, const float
                                      const float* beta, float* running_mean, float* running_var,
                                      int64_t* num_batches_tracked, float momentum, float eps, int act, int training,
                                      int M, int N, int K, float* y_out, float* out, float* save_mean,
-                                     float* save_invstd, void* stream) {
+                                     float* save_invstd, int groups, int stat_repeats, void* stream) {
   GDM_REQUIRE(x && w && gamma && beta && out && save_mean && save_invstd, "gdm_linear_bn_act_fwd: null pointer");
+  GDM_REQUIRE(groups >= 1 && stat_repeats >= 1, "gdm_linear_bn_act_fwd: groups and stat_repeats must be >= 1");
   GDM_REQUIRE(M >= 1 && M <= LB_M && N >= 1 && K >= 1, "gdm_linear_bn_act_fwd: M=%d outside 1..%d (or bad N/K)", M, LB_M);
   GDM_REQUIRE(!training || M > 1, "gdm_linear_bn_act_fwd: training-mode batch norm needs more than 1 row");
   GDM_REQUIRE(training || (running_mean && running_var), "gdm_linear_bn_act_fwd: eval mode needs running statistics");
@@ -232,11 +254,11 @@ extern "C" int gdm_linear_bn_act_fwd(const float* x, const float* w, const float
   if (vec)
     hipLaunchKernelGGL(linear_bn_act_kernel<true>, dim3((N + LB_N - 1) / LB_N), dim3(256), 0, (hipStream_t)stream, x, w,
                        bias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, act, training, M,
-                       N, K, y_out, out, save_mean, save_invstd);
+                       N, K, y_out, out, save_mean, save_invstd, groups, stat_repeats);
   else
     hipLaunchKernelGGL(linear_bn_act_kernel<false>, dim3((N + LB_N - 1) / LB_N), dim3(256), 0, (hipStream_t)stream, x, w,
                        bias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, act, training,
-                       M, N, K, y_out, out, save_mean, save_invstd);
+                       M, N, K, y_out, out, save_mean, save_invstd, groups, stat_repeats);
   GDM_LAUNCH_OK("gdm_linear_bn_act_fwd");
   return GDM_OK;
 }

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const void* __restrict__ co
                                                      void* __restrict__ dst, int dd, int flags) {
   const int K = KH * KW * C;
   const bool planar = flags & 1, tap_major = flags & 2;
+  const int act = (flags >> 4) & 3;             // fused activation (the generator's final sigmoid, SIMNN.py:110)
   const int64_t total = (int64_t)B * H * W * C;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % C);
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const void* __restrict__ co
       }
     }
     const int64_t di = planar ? (((int64_t)b * C + c) * H + h) * W + w : i;
-    store_from_f32(dst, dd, di, s);
+    store_from_f32(dst, dd, di, apply_act(s, act, 0.f));
   }
 }
 

@@ -686,7 +686,10 @@ constexpr int BD_WPX = BD_COLS + 4;            // stored columns: band column cl
 constexpr int BD_NPC = BD_COLS / 2 + 2;        // pooled columns touching the band (c0/2 - 1 .. c0/2 + 32)
 constexpr int BD_ITEMS = 2 * BD_NPC;           // pooled pixels expanded per step
 constexpr int BD_DCIT = (BD_ITEMS * 4 + 255) / 256;
-constexpr int BD_XW = 256;                     // x-window row stride in LDS (power of two: cheap gather offsets)
+#ifndef GDM_BD_XW
+#define GDM_BD_XW 256
+#endif
+constexpr int BD_XW = GDM_BD_XW;               // x-window row stride in LDS (>= BD_XCOLS = 136, multiple of 4)
 constexpr int BD_XCOLS = 2 * BD_COLS + 8;      // x-window columns 2c0-4 .. 2c0+131 (16-byte aligned start)
 template <typename T> struct BD {
   static constexpr int DC_ELEMS = BD_RING * BD_WPX * C2<T>::S32;
@@ -1025,7 +1028,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
             xo[r][0] = f; xo[r][1] = f; xo[r][2] = f; xo[r][3] = f;
             (void)xcol;
 #else
-            const float* xp = xcol + 2 * ir * XW + ((pos * 129u) & 0x101u);
+            const float* xp = xcol + 2 * ir * XW + (XW == 256 ? ((pos * 129u) & 0x101u) : (pos & 1u) + XW * (pos >> 1));
             xo[r][0] = xp[0]; xo[r][1] = xp[1]; xo[r][2] = xp[XW]; xo[r][3] = xp[XW + 1];
 #endif
           }

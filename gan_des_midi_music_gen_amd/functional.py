@@ -182,17 +182,22 @@ def _tap_major_weight(w, cache, slot):
     return wp
 
 
-def convT_forward(x2d, w, b, ih, iw, stride, pad, dt, cache=None, slot=0):
+def convT_forward(x2d, w, b, ih, iw, stride, pad, dt, cache=None, slot=0, act=ACT_NONE):
     """x2d (B*IH*IW, Cin) -> y (B*OH*OW, Cout) fp32 channels-last; w is torch's (Cin, Cout, KH, KW).
-    cache / slot: see _tap_major_weight."""
+    cache / slot: see _tap_major_weight.  act: activation fused into the scatter pass."""
     cin, cout, kh, kw = w.shape
     oh = (ih - 1) * stride - 2 * pad + kh
     ow = (iw - 1) * stride - 2 * pad + kw
     tap_major = cout >= 16               # with few output channels torch's order is already the contiguous one
     w2d = _tap_major_weight(w, cache, slot) if tap_major else w.view(cin, cout * kh * kw)
     cols = ops.gemm(x2d, w2d, compute=dt, out_dtype=F32)
+    if tap_major and ih == 1 and iw == 1 and stride == 1 and pad == 0:
+        # a 1x1 input (the generator's first layer, SIMNN.py:70): output pixel (oh, ow) IS tap (kh, kw) = (oh, ow) of the
+        # only input pixel, so the tap-major GEMM result already is the channels-last output -- no scatter pass
+        assert act == ACT_NONE
+        return cols.view(b * oh * ow, cout), oh, ow
     y = ops.col2im(cols, b=b, h=oh, w=ow, c=cout, kh=kh, kw=kw, stride=stride, pad=pad, oh=ih, ow=iw, out_dtype=F32,
-                   tap_major=tap_major)
+                   tap_major=tap_major, act=act)
     return y.view(b * oh * ow, cout), oh, ow
 
 
@@ -227,7 +232,9 @@ def simnn_gen_forward(noise, ws, bns, training, dt, cache=None):
     for li in range(4):
         stride, pad = _G_GEOM[li]
         w = ws[li]
-        y, oh, ow = convT_forward(x, w, b, ih, iw, stride, pad, dt, cache=cache, slot=li)
+        # the last layer's sigmoid (SIMNN.py:110) rides the scatter pass; backward only needs the activated output
+        y, oh, ow = convT_forward(x, w, b, ih, iw, stride, pad, dt, cache=cache, slot=li,
+                                  act=ACT_SIGMOID if li == 3 else ACT_NONE)
         if li < 3:
             gamma, beta, rm, rv, nbt = bns[li]
             out, mean, invstd = ops.bn_act_fwd(y, gamma, beta, rm, rv, nbt, act=ACT_RELU, out_dtype=F32,
@@ -235,8 +242,8 @@ def simnn_gen_forward(noise, ws, bns, training, dt, cache=None):
             saved.append((x, y, out, mean, invstd, ih, iw, oh, ow))
             x = out
         else:
-            out = ops.bias_act_fwd(y, None, act=ACT_SIGMOID)
-            saved.append((x, y, out, None, None, ih, iw, oh, ow))
+            out = y
+            saved.append((x, None, out, None, None, ih, iw, oh, ow))
         ih, iw = oh, ow
     c_out = ws[3].shape[1]
     # channels-last (B,20,20,C) -> (B,C,20,20); for the reference's C == 1 this is a free view
@@ -293,18 +300,24 @@ class SimnnGenFn(torch.autograd.Function):
 # ======================================================================================================================
 # Model 2 generators: 4 x [Linear -> BatchNorm1d -> Sigmoid] (MMGAN_MIDI_DES/network_tests.py:67-80, 102-115)
 # ======================================================================================================================
-def mlp_bn_sigmoid_forward(x, layers, training, dt, need_backward=True):
+def mlp_bn_sigmoid_forward(x, layers, training, dt, need_backward=True, groups=1, stat_repeats=1):
     """layers: list of (W (out,in), b, gamma, beta, rmean, rvar, nbt).  Returns (out fp32, saved).
 
     bf16 mode with <= 256 rows: one fused Linear+BN+Sigmoid launch per block (batch statistics never leave the
-    workgroup); otherwise GEMM + the three-launch batch norm (any batch size, exact-fp32 mode)."""
+    workgroup); otherwise GEMM + the three-launch batch norm (any batch size, exact-fp32 mode).
+    groups / stat_repeats (fused path only, forward only): x stacks ``groups`` batches that are normalised separately,
+    running statistics updated in order, each update applied ``stat_repeats`` times (ops.linear_bn_act_fwd)."""
     saved = []
     x = _f32c(x)
-    fused = dt == BF16 and x.shape[0] <= ops.linear_bn_act_max_rows() and (not training or x.shape[0] > 1)
+    rows = x.shape[0] // groups
+    fused = dt == BF16 and rows <= ops.linear_bn_act_max_rows() and (not training or rows > 1)
+    if (groups > 1 or stat_repeats > 1) and (not fused or need_backward):
+        raise ops.GdmError("stacked / repeated generator forwards exist on the fused forward-only path only")
     for (w, bias, gamma, beta, rm, rv, nbt) in layers:
         if fused:
             out, y, mean, invstd = ops.linear_bn_act_fwd(x, w, bias, gamma, beta, rm, rv, nbt, act=ACT_SIGMOID,
-                                                         training=training, save_y=need_backward)
+                                                         training=training, save_y=need_backward, groups=groups,
+                                                         stat_repeats=stat_repeats)
         else:
             y = ops.gemm(x, w.t(), bias_n=bias, compute=dt)
             out, mean, invstd = ops.bn_act_fwd(y, gamma, beta, rm, rv, nbt, act=ACT_SIGMOID, out_dtype=F32,

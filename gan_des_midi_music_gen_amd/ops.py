@@ -414,21 +414,28 @@ def linear_bn_act_max_rows():
 
 
 def linear_bn_act_fwd(x, w, bias, gamma, beta, running_mean, running_var, nbt, *, act, training=True, momentum=0.1,
-                      eps=1e-5, save_y=False):
-    """Linear + BatchNorm1d + activation in one launch (rows <= linear_bn_act_max_rows()).
+                      eps=1e-5, save_y=False, groups=1, stat_repeats=1):
+    """Linear + BatchNorm1d + activation in one launch (rows per group <= linear_bn_act_max_rows()).
+
+    groups > 1: x holds ``groups`` batches of equal size stacked along dim 0; each is normalised with its own batch
+    statistics and the running statistics are updated in that order (mean / invstd come back as (groups, N)).
+    stat_repeats: apply each running-statistics update that many times.
     Returns (out, y or None, save_mean, save_invstd)."""
     _need_gpu(x, w, bias, gamma, beta, running_mean, running_var, nbt)
     assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.is_contiguous() and w.is_contiguous()
     assert x.dtype == torch.float32 and w.dtype == torch.float32
-    m, k = x.shape
+    rows, k = x.shape
+    assert rows % groups == 0
+    m = rows // groups
     n = w.shape[0]
-    out = torch.empty((m, n), dtype=torch.float32, device=x.device)
-    y = torch.empty((m, n), dtype=torch.float32, device=x.device) if save_y else None
-    mean = torch.empty(n, dtype=torch.float32, device=x.device)
-    invstd = torch.empty(n, dtype=torch.float32, device=x.device)
+    out = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+    y = torch.empty((rows, n), dtype=torch.float32, device=x.device) if save_y else None
+    shape = (n,) if groups == 1 else (groups, n)
+    mean = torch.empty(shape, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(shape, dtype=torch.float32, device=x.device)
     _call("gdm_linear_bn_act_fwd", _p(x), _p(w), _p(bias), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
           _p(nbt), float(momentum), float(eps), act, 1 if training else 0, m, n, k, _p(y), _p(out), _p(mean),
-          _p(invstd), _stream())
+          _p(invstd), int(groups), int(stat_repeats), _stream())
     return out, y, mean, invstd
 
 
@@ -499,14 +506,16 @@ def im2col(src, *, planar, b, h, w, c, kh, kw, stride, pad, out_dtype):
     return cols, oh, ow
 
 
-def col2im(cols, *, b, h, w, c, kh, kw, stride, pad, oh, ow, out_dtype, planar=False, tap_major=False):
-    """tap_major: the columns of ``cols`` are ordered (kh, kw, c) instead of torch's (c, kh, kw)."""
+def col2im(cols, *, b, h, w, c, kh, kw, stride, pad, oh, ow, out_dtype, planar=False, tap_major=False, act=ACT_NONE):
+    """tap_major: the columns of ``cols`` are ordered (kh, kw, c) instead of torch's (c, kh, kw); act: fused
+    activation on the scattered sum (ACT_NONE / ACT_RELU / ACT_SIGMOID)."""
+    assert act in (ACT_NONE, ACT_RELU, ACT_SIGMOID)
     _need_gpu(cols)
     assert cols.is_contiguous() and cols.shape == (b * oh * ow, c * kh * kw)
     shape = (b, c, h, w) if planar else (b, h, w, c)
     dst = torch.empty(shape, dtype=_TORCH_DT[out_dtype], device=cols.device)
     _call("gdm_col2im", _p(cols), gdm_dtype(cols), b, h, w, c, kh, kw, stride, pad, oh, ow, _p(dst),
-                                 out_dtype, (1 if planar else 0) | (2 if tap_major else 0), _stream())
+                                 out_dtype, (1 if planar else 0) | (2 if tap_major else 0) | (act << 4), _stream())
     return dst
 
 

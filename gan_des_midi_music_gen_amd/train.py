@@ -558,6 +558,37 @@ class MmganTrainer(_TrainerBase):
     def _fused_ok(self, t):
         return self.dt == ops.BF16 and ops.dcnn_fused_supported(t)
 
+    def _generators_forward_both(self, noise1, noise2, beats, g1_in_a, g1_in_b, streams):
+        """Both forwards each generator makes in one iteration (network_tests.py:294 and 312) in ONE chain of four
+        launches per generator: generator 1's two input batches are stacked (two BatchNorm groups per launch, running
+        statistics updated in call order); the beat generator sees identical inputs both times, so its second forward
+        is its first one with the running-statistics update applied twice.  The outputs do not depend on the
+        discriminator, so the whole chain runs at the start of the iteration, beside the discriminator step.
+        Returns (g1_a, g2_a, g1_b, g2_b); falls back to two sequential forwards where the fused block does not apply."""
+        mm, dt = self.mm, self.dt
+        b = len(noise1)
+        fused = (dt == ops.BF16 and 1 < b <= ops.linear_bn_act_max_rows() and mm.generator1.training
+                 and mm.generator2.training)
+        if not fused:
+            g1a, g2a = self._generators_forward(noise1, noise2, beats, g1_in_a, streams)
+            g1b, g2b = self._generators_forward(noise1, noise2, beats, g1_in_b, streams)
+            return g1a, g2a, g1b, g2b
+        if g1_in_a is None:    # network_tests.py:83-84: drawn on the CPU generator, call by call
+            g1_in_a = torch.randn(b, mm.generator1.input_tensor_dim).to(noise1.device)
+        if g1_in_b is None:
+            g1_in_b = torch.randn(b, mm.generator1.input_tensor_dim).to(noise1.device)
+        s1, s2 = streams if streams is not None else (None, None)
+        with torch.cuda.stream(s1 if s1 is not None else torch.cuda.current_stream()):
+            x1 = torch.cat((torch.cat((noise1, g1_in_a), dim=1), torch.cat((noise1, g1_in_b), dim=1)), dim=0)
+            o1, _ = Fn.mlp_bn_sigmoid_forward(x1, self._layers(mm.generator1), True, dt, need_backward=False, groups=2)
+        with torch.cuda.stream(s2 if s2 is not None else torch.cuda.current_stream()):
+            x2 = torch.cat((noise2, beats), dim=1)
+            o2, _ = Fn.mlp_bn_sigmoid_forward(x2, self._layers(mm.generator2), True, dt, need_backward=False,
+                                              stat_repeats=2)
+        a = mm.generator1.adj_size
+        g1 = o1.view(2, b, -1, a[0], a[1])
+        return g1[0], o2, g1[1], o2
+
     @torch.no_grad()
     def step(self, piano_roll, durations, beats, noise1, noise2, fake_a, fake_b, g1_in_a=None, g1_in_b=None):
         """fake_a / fake_b: (B,2,128,T) tensors or callables ``f(g1_out, g2_out) -> tensor`` standing in for the
@@ -566,7 +597,7 @@ class MmganTrainer(_TrainerBase):
         The iteration is three pieces -- everything up to the gradient (``_part_a``), the data-parallel exchange, Adam and
         the generator step (``_part_b``) -- so that with more than one rank the two compute pieces can be replayed as
         hipGraphs around the eager collective (``capture`` / ``replay``)."""
-        self._part_a(piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a)
+        self._part_a(piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a, g1_in_b)
         self._reduce()
         self._part_b(piano_roll, beats, noise1, noise2, fake_b, g1_in_b)
         self.iterations += 1
@@ -577,9 +608,10 @@ class MmganTrainer(_TrainerBase):
             self._gen_stream = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
         return self._gen_stream
 
-    def _part_a(self, piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a):
-        """D step up to the gradient (network_tests.py:293-307): generators' first forward on side streams beside the
-        discriminator's forward + loss + backward; every branch is joined before returning."""
+    def _part_a(self, piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a, g1_in_b):
+        """D step up to the gradient (network_tests.py:293-307): the generators (both forwards of the iteration, see
+        _generators_forward_both) on side streams beside the discriminator's forward + loss + backward; every branch
+        is joined before returning."""
         dt = self.dt
         w1, b1, w2, b2, wf, bf = self.d.views
         gv = self.d.grad_views
@@ -596,8 +628,9 @@ class MmganTrainer(_TrainerBase):
         self.d.extra[1:4].zero_()
         for sd in sides:
             sd.wait_stream(main)
-        g1, g2 = self._generators_forward(noise1, noise2, beats, g1_in_a, sides)
+        g1, g2, g1b, g2b = self._generators_forward_both(noise1, noise2, beats, g1_in_a, g1_in_b, sides)
         self.last_g1, self.last_g2 = g1, g2
+        self._gen_b = (g1b, g2b)           # second forward's outputs: the bridge of the generator step consumes them
         if callable(fake_a):
             for sd in sides:
                 main.wait_stream(sd)
@@ -627,25 +660,18 @@ class MmganTrainer(_TrainerBase):
             main.wait_stream(sd)
 
     def _part_b(self, piano_roll, beats, noise1, noise2, fake_b, g1_in_b):
-        """Adam (308), then the "G" step (311-315): both generators run again (2nd BN statistics update), D forward on
-        the new fake (+ the dead backward in faithful mode)."""
+        """Adam (308), then the "G" step (311-315): D forward on the bridge's output for the generators' second forward
+        (which ran at the start of the iteration: _generators_forward_both) + the dead backward in faithful mode."""
         dt = self.dt
         w1, b1, w2, b2, wf, bf = self.d.views
         gv = self.d.grad_views
         t = piano_roll.shape[2]
         fused = self._fused_ok(t)
-        main = torch.cuda.current_stream()
-        sides = self._sides(piano_roll.device)
         self._adam()
         if fused:
             ops.dcnn_pack(w1, b1, w2, b2, wf, bf, t, out=self._pack)     # weights changed: refresh in place
-        for sd in sides:
-            sd.wait_stream(main)
-        g1b, g2b = self._generators_forward(noise1, noise2, beats, g1_in_b, sides)
         if callable(fake_b):
-            for sd in sides:
-                main.wait_stream(sd)
-            fake_b = fake_b(g1b, g2b)
+            fake_b = fake_b(*self._gen_b)      # the generators' second forward ran at the start of the iteration
         if fused:
             if self.elide:
                 ops.dcnn_fused(Fn._f32c(fake_b), None, t, 1.0, 1.0, self._pack, loss_out=self.loss_g, want_grad=False)
@@ -661,8 +687,6 @@ class MmganTrainer(_TrainerBase):
             else:
                 _, dlg = ops.bce_with_logits(logits_g.view(-1), 1.0, loss_out=self.loss_g)
                 Fn.dcnn_backward(saved_g, dlg, w2, wf, dt)     # dead values (only D's .grad in the reference)
-        for sd in sides:
-            main.wait_stream(sd)
 
     # ---- hipGraph capture for fixed input buffers --------------------------------------------------------------------
     def capture(self, piano_roll, durations, beats, noise1, noise2, fake_a, fake_b, g1_in_a, g1_in_b):
@@ -693,7 +717,7 @@ class MmganTrainer(_TrainerBase):
         else:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
-                self._part_a(piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a)
+                self._part_a(piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a, g1_in_b)
             pool = ga.pool()
             with torch.cuda.graph(gb, pool=pool):
                 self._part_b(piano_roll, beats, noise1, noise2, fake_b, g1_in_b)

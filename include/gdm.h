@@ -170,12 +170,16 @@ int gdm_simnn_head(const float* h1, const float* w2, const float* b2, int n, int
  * (network_tests.py:75-80,110-115: aten::addmm + native_batch_norm + sigmoid).  x (M,K), w (N,K) fp32 row-major;
  * bf16 MFMA operands, fp32 accumulation, exact two-pass batch statistics kept inside the workgroup that owns the
  * columns; running statistics / num_batches_tracked updated in training mode.  y_out (M,N) = pre-norm values,
- * optional (backward needs them).                                                                                    */
+ * optional (backward needs them).
+ * groups >= 1: x, y_out, out hold `groups` batches of M rows one after the other (save_mean / save_invstd: groups x N);
+ * every batch is normalised with its own statistics and the running statistics take the updates in batch order -- the
+ * two forwards a generator makes per training iteration (network_tests.py:294, 312) in one launch.  stat_repeats >= 1
+ * applies each running-statistics update that many times (a forward repeated on identical inputs).                  */
 int gdm_linear_bn_act_max_rows(void);
 int gdm_linear_bn_act_fwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                           float eps, int act, int training, int M, int N, int K, float* y_out, float* out,
-                          float* save_mean, float* save_invstd, void* stream);
+                          float* save_mean, float* save_invstd, int groups, int stat_repeats, void* stream);
 /* DiscriminatorCNN(roll_size=(2,128,T)) forward + BCE-with-logits loss + full backward as one persistent kernel that
  * keeps a whole sample and its activations in LDS (network_tests.py:147-160 and the criterion calls at 304-305, 313;
  * replaces aten::convolution x2, leaky_relu x2, addmm, binary_cross_entropy_with_logits and their backwards).
@@ -204,7 +208,7 @@ int gdm_im2col(const void* src, int src_dtype, int src_planar, int B, int H, int
 /* dst[b,h,w,c] = sum over (oh,ow,kh,kw) with oh*stride-pad+kh==h, ow*stride-pad+kw==w of cols[(b,oh,ow),(c,kh,kw)].
  * dst_planar: bit 0 = write (B,C,H,W) instead of channels-last; bit 1 = the columns of `cols` are ordered (kh,kw,c)
  * (tap-major: what a GEMM with the weight permuted to (Cin, KH, KW, Cout) produces -- coalesced reads) instead of
- * torch's (c,kh,kw).                                                                                               */
+ * torch's (c,kh,kw); bits 4-5 = GDM_ACT_* applied to the sum (RELU / SIGMOID; LEAKY is not offered here).            */
 int gdm_col2im(const void* cols, int cols_dtype, int B, int H, int W, int C, int KH, int KW, int stride, int pad,
                int OH, int OW, void* dst, int dst_dtype, int dst_planar, void* stream);
 

@@ -262,6 +262,37 @@ def test_fused_linear_bn_sigmoid_matches_unfused_path():
         assert int(nbt.item()) == 1
 
 
+def test_stacked_and_repeated_generator_blocks_equal_sequential_launches():
+    """groups=2: two batches in one launch == two launches, bit for bit (outputs, batch statistics, running statistics
+    in call order, num_batches_tracked); stat_repeats=2 == the same launch twice."""
+    from gan_des_midi_music_gen_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for m, k, n in ((256, 100, 256), (16, 64, 4096), (40, 128, 20)):
+        xa, xb = torch.randn(m, k, generator=g).to(DEV), (torch.randn(m, k, generator=g) * 3 + 1).to(DEV)
+        w, bias = (torch.randn(n, k, generator=g) * 0.1).to(DEV), torch.randn(n, generator=g).to(DEV)
+        gamma, beta = (torch.rand(n, generator=g) + 0.5).to(DEV), torch.randn(n, generator=g).to(DEV)
+
+        def fresh():
+            return torch.zeros(n, device=DEV), torch.ones(n, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+
+        rm1, rv1, nbt1 = fresh()
+        oa, _, ma, ia = ops.linear_bn_act_fwd(xa, w, bias, gamma, beta, rm1, rv1, nbt1, act=ops.ACT_SIGMOID)
+        ob, _, mb, ib = ops.linear_bn_act_fwd(xb, w, bias, gamma, beta, rm1, rv1, nbt1, act=ops.ACT_SIGMOID)
+        rm2, rv2, nbt2 = fresh()
+        o2, _, m2, i2 = ops.linear_bn_act_fwd(torch.cat([xa, xb]), w, bias, gamma, beta, rm2, rv2, nbt2,
+                                              act=ops.ACT_SIGMOID, groups=2)
+        assert torch.equal(o2[:m], oa) and torch.equal(o2[m:], ob)
+        assert torch.equal(m2[0], ma) and torch.equal(m2[1], mb) and torch.equal(i2[0], ia) and torch.equal(i2[1], ib)
+        assert torch.equal(rm2, rm1) and torch.equal(rv2, rv1) and int(nbt2) == int(nbt1) == 2
+        rm3, rv3, nbt3 = fresh()
+        ops.linear_bn_act_fwd(xa, w, bias, gamma, beta, rm3, rv3, nbt3, act=ops.ACT_SIGMOID)
+        ops.linear_bn_act_fwd(xa, w, bias, gamma, beta, rm3, rv3, nbt3, act=ops.ACT_SIGMOID)
+        rm4, rv4, nbt4 = fresh()
+        o4, _, _, _ = ops.linear_bn_act_fwd(xa, w, bias, gamma, beta, rm4, rv4, nbt4, act=ops.ACT_SIGMOID,
+                                            stat_repeats=2)
+        assert torch.equal(o4, oa) and torch.equal(rm4, rm3) and torch.equal(rv4, rv3) and int(nbt4) == 2
+
+
 def test_graph_replay_matches_eager_bf16():
     b = 32
     outs = []
