@@ -1,0 +1,23 @@
+# Round-2 evidence in one call: kernel stats (graph / single-stream eager / model 2), HBM traffic passes, SQ counters,
+# bench lines (default, eager, elided, fp32, model 2 graph + eager).  Summaries are copied to profiles/ afterwards
+# (tools/collect_profiles.py r02).
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+rm -rf gpurun_out/final_simnn gpurun_out/final_simnn_eager gpurun_out/final_mmgan gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_a gpurun_out/pmc_b
+bash tools/profile_final.sh
+bash tools/pmc_traffic.sh > /dev/null 2>&1
+python tools/pmc_traffic_summary.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/hbm_traffic.json > gpurun_out/hbm_traffic.txt
+python tools/step_breakdown.py gpurun_out/final_simnn_eager > gpurun_out/step_breakdown.txt
+bash tools/pmc_simnn.sh > /dev/null 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_a gpurun_out/pmc_b > gpurun_out/pmc_sq.txt
+python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+python bench.py --workload mmgan > gpurun_out/bench_mmgan.json 2>> gpurun_out/bench_default.err
+python bench.py --no-cpu-baseline --no-roofline --no-graph > gpurun_out/bench_simnn_eager.json 2>> gpurun_out/bench_default.err
+python bench.py --no-cpu-baseline --no-roofline --mode elided > gpurun_out/bench_simnn_elided.json 2>> gpurun_out/bench_default.err
+python bench.py --no-cpu-baseline --no-roofline --no-pipeline > gpurun_out/bench_simnn_nopipeline.json 2>> gpurun_out/bench_default.err
+python bench.py --no-cpu-baseline --dtype fp32 > gpurun_out/bench_simnn_fp32.json 2>> gpurun_out/bench_default.err
+python bench.py --no-cpu-baseline --no-roofline --workload mmgan --no-graph > gpurun_out/bench_mmgan_eager.json 2>> gpurun_out/bench_default.err
+python bench.py --no-cpu-baseline --no-roofline --workload mmgan --batch 16 > gpurun_out/bench_mmgan_b16.json 2>> gpurun_out/bench_default.err
+find gpurun_out -name "*.db" -delete
+grep -h metric gpurun_out/bench_*.json | cut -c1-210
+cat gpurun_out/step_breakdown.txt | head -40
