@@ -286,50 +286,6 @@ __global__ __launch_bounds__(1024) void bn_finalize(const float* __restrict__ ws
   }
 }
 
-// bn_finalize and bn_apply in one launch: every workgroup merges the per-chunk Welford triples of all channels itself
-// (<= 64 chunks x C triples, L2-resident: cheaper than a launch boundary for these latency-bound layers), in chunk
-// order -- every workgroup arrives at the same bits -- keeps scale / shift per channel in LDS and then normalises its
-// share of the rows; workgroup 0 also publishes the statistics (save_mean / save_invstd, running statistics,
-// num_batches_tracked).
-constexpr int BN_FA_MAXC = 512;
-__global__ __launch_bounds__(256) void bn_finalize_apply(const float* __restrict__ y, const float* __restrict__ ws,
-                                                         int chunks, int rows, int C, float momentum, float eps,
-                                                         const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta,
-                                                         float* __restrict__ running_mean,
-                                                         float* __restrict__ running_var, int64_t* __restrict__ nbt,
-                                                         float* __restrict__ save_mean,
-                                                         float* __restrict__ save_invstd, int act,
-                                                         void* __restrict__ out, int out_dtype) {
-  __shared__ float sm[BN_FA_MAXC], sc[BN_FA_MAXC], sh[BN_FA_MAXC];
-  for (int c = threadIdx.x; c < C; c += 256) {
-    Welford t{0.f, 0.f, 0.f};
-    for (int k = 0; k < chunks; ++k) {
-      const float* o = ws + ((int64_t)k * C + c) * 3;
-      welford_merge(t, Welford{o[0], o[1], o[2]});
-    }
-    const float invstd = 1.0f / sqrtf(t.m2 / (float)rows + eps);
-    sm[c] = t.mean;
-    sc[c] = invstd * gamma[c];
-    sh[c] = beta[c];
-    if (blockIdx.x == 0) {
-      save_mean[c] = t.mean;
-      save_invstd[c] = invstd;
-      if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * t.mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (t.m2 / (float)max(rows - 1, 1));
-      }
-    }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
-  __syncthreads();
-  const int64_t total = (int64_t)rows * C, stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
-    const int c = (int)(i % C);
-    store_from_f32(out, out_dtype, i, apply_act((y[i] - sm[c]) * sc[c] + sh[c], act, 0.f));      // bn_apply's expression
-  }
-}
-
 __global__ __launch_bounds__(256) void bn_eval_stats(const float* __restrict__ running_mean,
                                                      const float* __restrict__ running_var, int C, float eps,
                                                      float* __restrict__ save_mean, float* __restrict__ save_invstd) {
@@ -563,16 +519,6 @@ extern "C" int gdm_bn_act_fwd(const float* y, int rows, int channels, const floa
     while (cw / 2 >= C && cw > 1) cw /= 2;                      // lanes per row: power of two >= min(C, 64)
     hipLaunchKernelGGL(bn_partial_stats, dim3((C + 63) / 64, chunks), dim3(256), 0, s, y, rows, C, chunk_rows, cw,
                        (float*)workspace);
-    if (C <= BN_FA_MAXC) {
-      const int64_t total_fa = (int64_t)rows * C;
-      int64_t wgs = (total_fa + 256 * 8 - 1) / (256 * 8);          // >= 8 elements per thread: the prologue is per workgroup
-      wgs = wgs < 1 ? 1 : (wgs > 512 ? 512 : wgs);
-      hipLaunchKernelGGL(bn_finalize_apply, dim3((unsigned)wgs), dim3(256), 0, s, y, (const float*)workspace, chunks,
-                         rows, C, momentum, eps, gamma, beta, running_mean, running_var, num_batches_tracked, save_mean,
-                         save_invstd, act, out, out_dtype);
-      GDM_LAUNCH_OK("gdm_bn_act_fwd");
-      return GDM_OK;
-    }
     hipLaunchKernelGGL(bn_finalize, dim3((C + 63) / 64), dim3(1024), 0, s, (const float*)workspace, chunks, rows, C,
                        momentum, eps, running_mean, running_var, num_batches_tracked, save_mean, save_invstd);
   } else {

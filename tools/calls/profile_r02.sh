@@ -3,6 +3,7 @@
 # (tools/collect_profiles.py r02).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
+python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_r02.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu_r02.log; tail -3 gpurun_out/pytest_gpu_r02.log
 rm -rf gpurun_out/final_simnn gpurun_out/final_simnn_eager gpurun_out/final_mmgan gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_a gpurun_out/pmc_b
 bash tools/profile_final.sh
 bash tools/pmc_traffic.sh > /dev/null 2>&1
