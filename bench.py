@@ -292,12 +292,21 @@ def main():
         if args.workload == "simnn":
             # the timed entry point runs on the 2B batch (D step) and, in faithful mode, on B (the dead backward)
             samples_per_launch = 2.0 * args.batch if args.mode == "elided" else 1.5 * args.batch
-            achieved = dk["bytes_per_sample"] * samples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dk["kernel"],
-                        "algorithmic_bytes_per_launch": int(dk["bytes_per_sample"] * samples_per_launch),
-                        "avg_launch_ms": round(avg_ms, 4), "avg_launch_ms_alone": round(alone_ms, 4),
-                        "avg_launch_ms_in_timed_schedule": round(sched_ms, 4), "launches_timed": launches}
+            if args.dtype == "bf16":
+                achieved = dk["bytes_per_sample"] * samples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+                roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": dk["kernel"],
+                            "algorithmic_bytes_per_launch": int(dk["bytes_per_sample"] * samples_per_launch)}
+            else:
+                # exact-fp32 mode: 192 FLOP per algorithmic byte against a ridge of 157 TF / 8 TB/s = 20 FLOP/B -> the
+                # binding roof is the fp32 MFMA
+                tflops = dk["flops_per_sample"] * samples_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+                roofline = {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                            "kernel": dk["kernel"],
+                            "algorithmic_flops_per_launch": int(dk["flops_per_sample"] * samples_per_launch)}
+            roofline.update({"avg_launch_ms": round(avg_ms, 4), "avg_launch_ms_alone": round(alone_ms, 4),
+                             "avg_launch_ms_in_timed_schedule": round(sched_ms, 4), "launches_timed": launches})
         else:
             # the timed entry point runs on the 2B batch (D step) and on B (the generator step's pass through D)
             samples_per_launch = 1.5 * args.batch

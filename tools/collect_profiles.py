@@ -30,6 +30,15 @@ copy(os.path.join(out, "step_breakdown.txt"), f"{tag}_simnn_b256_bf16_step_break
 copy(os.path.join(out, "bench_default.json"), f"{tag}_bench_default.json")
 copy(os.path.join(out, "bench_mmgan.json"), f"{tag}_bench_mmgan.json")
 copy(os.path.join(out, "pmc_ops_summary.txt"), f"{tag}_conv_kernels_b512_pmc_sq.txt")
+for name in ("bench_simnn_eager", "bench_simnn_elided", "bench_simnn_nopipeline", "bench_simnn_fp32", "bench_mmgan_eager",
+             "bench_mmgan_b16"):
+    copy(os.path.join(out, name + ".json"), f"{tag}_{name}.json")
+copy(os.path.join(out, "pytest_gpu_r02.log"), f"{tag}_pytest_gpu.log")
+copy(os.path.join(out, "parity_r02.jsonl"), f"{tag}_parity_measurements.jsonl")
+copy(os.path.join(out, "r2_ko1.log"), f"{tag}_fused_bwd_knockout.txt")
+copy(os.path.join(out, "r2_overlap.log"), f"{tag}_conv_bwd_side_by_side.txt")
+copy(os.path.join(out, "r2_streams.log"), f"{tag}_stream_concurrency.txt")
+copy(os.path.join(out, "r2_stamps_occ.log"), f"{tag}_stamps_vs_occupancy.txt")
 
 # bench.py reads the dominant kernel's measured HBM bytes per launch from profiles/traffic.json
 src = os.path.join(out, "hbm_traffic.json")
