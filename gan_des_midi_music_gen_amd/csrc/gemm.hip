@@ -40,9 +40,12 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = kbeg; k0 < kend; k0 += KT) {
-    constexpr int PER = BM * KT / NT;
-    float va[PER], vb[PER];
+  // Register prefetch: the loads of k-tile i+1 are issued right after tile i has been handed to LDS, so they fly during
+  // tile i's MFMAs (these launches run one or two workgroups per CU: without it every k-tile paid a full HBM round trip
+  // in front of 32 MFMAs -- exact-fp32 fc1 products ran at a third of what the matrix pipe allows).
+  constexpr int PER = BM * KT / NT;
+  float va[PER], vb[PER];
+  auto load_tile = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int idx = t + NT * i;
@@ -59,6 +62,9 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
       const int gn = n0 + n, gk = k0 + k;
       vb[i] = (gn < g.N && gk < kend) ? to_f32(B[(int64_t)gk * g.sbk + (int64_t)gn * g.sbn]) : 0.f;
     }
+  };
+  if (kbeg < kend) load_tile(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += KT) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int idx = t + NT * i;
@@ -70,6 +76,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
       Bs[n * LD + kb] = from_f32<CT>(vb[i]);
     }
     __syncthreads();
+    if (k0 + KT < kend) load_tile(k0 + KT);
     if constexpr (sizeof(CT) == 4) {
 #pragma unroll
       for (int ks = 0; ks < KT / 4; ++ks) {

@@ -31,16 +31,22 @@ __global__ __launch_bounds__(256) void im2col_kernel(const void* __restrict__ sr
   }
 }
 
+// IT = index type: int when every index fits 32 bits (always, for this path's tensors) -- 64-bit divisions cost ~100
+// instructions each and this kernel does four per element; int64_t otherwise.
+template <typename IT>
 __global__ __launch_bounds__(256) void col2im_kernel(const void* __restrict__ cols, int cd, int B, int H, int W, int C,
                                                      int KH, int KW, int stride, int pad, int OH, int OW,
                                                      void* __restrict__ dst, int dd, int flags) {
   const int K = KH * KW * C;
   const bool planar = flags & 1, tap_major = flags & 2;
   const int act = (flags >> 4) & 3;             // fused activation (the generator's final sigmoid, SIMNN.py:110)
-  const int64_t total = (int64_t)B * H * W * C;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  const IT total = (IT)B * H * W * C;
+  for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < total; i += (IT)gridDim.x * 256) {
     const int c = (int)(i % C);
-    const int w = (int)((i / C) % W), h = (int)((i / ((int64_t)C * W)) % H), b = (int)(i / ((int64_t)C * W * H));
+    const IT pix = i / C;
+    const int w = (int)(pix % W);
+    const IT row = pix / W;
+    const int h = (int)(row % H), b = (int)(row / H);
     float s = 0.f;
     // only the taps that can hit this output: kh = (h + pad) mod stride, + stride, ... with 0 <= oh < OH (a stride-2
     // 4x4 kernel has 2x2 of them, not 16: the kernel is bound by this index arithmetic, not by memory)
@@ -56,10 +62,10 @@ __global__ __launch_bounds__(256) void col2im_kernel(const void* __restrict__ co
         const int ow = (wp - kw) / stride;
         // tap-major columns ((kh,kw) slow, c fast): the lanes of a wave (consecutive c) read consecutive elements
         const int col = tap_major ? (kh * KW + kw) * C + c : (c * KH + kh) * KW + kw;
-        s += load_as_f32(cols, cd, (((int64_t)b * OH + oh) * OW + ow) * K + col);
+        s += load_as_f32(cols, cd, (int64_t)(((IT)b * OH + oh) * OW + ow) * K + col);
       }
     }
-    const int64_t di = planar ? (((int64_t)b * C + c) * H + h) * W + w : i;
+    const int64_t di = planar ? (((int64_t)b * C + c) * H + h) * W + w : (int64_t)i;
     store_from_f32(dst, dd, di, apply_act(s, act, 0.f));
   }
 }
@@ -154,8 +160,12 @@ extern "C" int gdm_col2im(const void* cols, int cols_dtype, int B, int H, int W,
               "gdm_col2im: bad geometry");
   GDM_REQUIRE(gdm_dtype_ok(dst_dtype) && gdm_dtype_ok(cols_dtype), "gdm_col2im: bad dtype");
   const int64_t total = (int64_t)B * H * W * C;
-  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, cols, cols_dtype, B, H,
-                     W, C, KH, KW, stride, pad, OH, OW, dst, dst_dtype, dst_planar);
+  if (total < ((int64_t)1 << 31) && (int64_t)B * OH * OW < ((int64_t)1 << 31))
+    hipLaunchKernelGGL(col2im_kernel<int>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, cols, cols_dtype, B,
+                       H, W, C, KH, KW, stride, pad, OH, OW, dst, dst_dtype, dst_planar);
+  else
+    hipLaunchKernelGGL(col2im_kernel<int64_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, cols,
+                       cols_dtype, B, H, W, C, KH, KW, stride, pad, OH, OW, dst, dst_dtype, dst_planar);
   GDM_LAUNCH_OK("gdm_col2im");
   return GDM_OK;
 }

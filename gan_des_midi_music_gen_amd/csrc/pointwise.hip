@@ -295,12 +295,14 @@ __global__ __launch_bounds__(256) void bn_eval_stats(const float* __restrict__ r
   save_invstd[c] = 1.0f / sqrtf(running_var[c] + eps);
 }
 
-__global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ y, int64_t total, int C,
+// (IT: 32-bit element indices when they fit -- a 64-bit modulo per element made this pass instruction-bound)
+template <typename IT>
+__global__ __launch_bounds__(256) void bn_apply(const float* __restrict__ y, int64_t total64, int C,
                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
                                                 int act, void* __restrict__ out, int out_dtype) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+  const IT total = (IT)total64, stride = (IT)gridDim.x * 256;
+  for (IT i = (IT)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
     const int c = (int)(i % C);
     const float alpha = invstd[c] * gamma[c];
     const float v = (y[i] - mean[c]) * alpha + beta[c];
@@ -527,8 +529,12 @@ extern "C" int gdm_bn_act_fwd(const float* y, int rows, int channels, const floa
                        save_mean, save_invstd);
   }
   const int64_t total = (int64_t)rows * C;
-  hipLaunchKernelGGL(bn_apply, dim3(grid_for(total)), dim3(256), 0, s, y, total, C, gamma, beta, save_mean,
-                     save_invstd, act, out, out_dtype);
+  if (total < ((int64_t)1 << 31))
+    hipLaunchKernelGGL(bn_apply<int>, dim3(grid_for(total)), dim3(256), 0, s, y, total, C, gamma, beta, save_mean,
+                       save_invstd, act, out, out_dtype);
+  else
+    hipLaunchKernelGGL(bn_apply<int64_t>, dim3(grid_for(total)), dim3(256), 0, s, y, total, C, gamma, beta, save_mean,
+                       save_invstd, act, out, out_dtype);
   GDM_LAUNCH_OK("gdm_bn_act_fwd");
   return GDM_OK;
 }

@@ -893,7 +893,12 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
   // the up to three output rows it touches, and the weight fragments of all nine taps stay in registers for the whole
   // kernel (bf16): 18 LDS fragment reads per 36 MFMAs.
   bf16x8 afr[sizeof(T) == 2 ? 9 : 1];
+  float afw[sizeof(T) == 4 ? 72 : 1];
   int cb[3];
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int k = 0; k < 72; ++k) afw[k] = w_s[lr * KP + 4 * k + lg];
+  }
   if constexpr (sizeof(T) == 2) {
 #pragma unroll
     for (int ks = 0; ks < 9; ++ks) afr[ks] = *(const bf16x8*)&w_s[lr * KP + 32 * ks + 8 * lg];
@@ -975,22 +980,26 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
           }
         }
       } else {
-#pragma unroll 1
+        // exact-fp32 mode: the weight fragments of all nine taps live in registers (72 per lane, loaded once per
+        // kernel), so a v_mfma_f32_16x16x4_f32 costs one LDS read (the gradient value, shared by up to three output
+        // rows) instead of two; the eight reads of a (row, tap column) are issued together ahead of their MFMAs
+#pragma unroll
         for (int rr = 0; rr < ROWS + 2; ++rr) {
           const int ro = ((ROWS * rq - 1 + rr) & (BD_RING - 1)) * BD_WPX;
 #pragma unroll
-          for (int aw = 0; aw < 3; ++aw)
-#pragma unroll 2
-            for (int o4 = 0; o4 < 8; ++o4) {
-              const float bb = dc_s[(ro + 16 * wv + lr + aw + 1) * S32 + 4 * o4 + lg];
+          for (int aw = 0; aw < 3; ++aw) {
+            float bb[8];
+#pragma unroll
+            for (int o4 = 0; o4 < 8; ++o4) bb[o4] = dc_s[(ro + 16 * wv + lr + aw + 1) * S32 + 4 * o4 + lg];
+#pragma unroll
+            for (int o4 = 0; o4 < 8; ++o4)
 #pragma unroll
               for (int ah = 2; ah >= 0; --ah) {
                 const int ir = rr - ah;
                 if (ir < 0 || ir >= ROWS) continue;
-                const float a = w_s[lr * KP + 4 * ((3 * ah + aw) * 8 + o4) + lg];
-                acc[ir] = mfma16(a, bb, acc[ir]);
+                acc[ir] = mfma16(afw[(3 * ah + aw) * 8 + o4], bb[o4], acc[ir]);
               }
-            }
+          }
         }
       }
       STAMP(2);

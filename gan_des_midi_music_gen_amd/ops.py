@@ -105,7 +105,10 @@ def default_split_k(m, n, k, compute):
     ktiles = (k + kt - 1) // kt
     if tiles >= 128 or ktiles < 32:
         return 1
-    return max(1, min(ktiles // 8, (256 + tiles - 1) // tiles))
+    # bf16: ~256 workgroups of 128x128 (the fast kernel keeps two k-tiles in flight); exact fp32: 64x64 tiles hold 17 KB
+    # of LDS, so ~768 workgroups (three per CU) hide each other's load latency
+    target = 256 if compute == BF16 else 768
+    return max(1, min(ktiles // 8, (target + tiles - 1) // tiles))
 
 
 def gemm(a, b, *, bias_n=None, bias_m=None, act=ACT_NONE, slope=0.0, out_dtype=None, compute=F32, split_k=None,
