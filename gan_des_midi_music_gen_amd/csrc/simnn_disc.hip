@@ -549,26 +549,34 @@ __device__ __forceinline__ void conv2_fwd_tile(const T* __restrict__ in_s, const
           for (int i = 0; i < 2; ++i) acc[i][d][j] = mfma16(a[ks & 1][i], bb[ks & 1][d][j], acc[i][d][j]);
     }
   } else {
-#pragma unroll 2
-    for (int ks = 0; ks < 36; ++ks) {
-      const int tap = ks >> 2, ci = 4 * (ks & 3) + lg;
+    // exact-fp32 mode: four k-steps (one tap) at a time -- the eight weight reads and sixteen activation reads of a tap are
+    // issued together, ahead of its 32 MFMAs (two dependent LDS reads in front of every MFMA pair left the fp32 matrix
+    // pipe waiting)
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
       const int kh = tap / 3, kw = tap % 3;
-      float a[2], bb[2][2];
+      float a[4][2], bb[4][2][2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = w_s[(arow + 4 * i) * KP + 4 * ks + lg];
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int ks = 4 * tap + k4, ci = 4 * k4 + lg;
 #pragma unroll
-      for (int d = 0; d < 2; ++d)
+        for (int i = 0; i < 2; ++i) a[k4][i] = w_s[(arow + 4 * i) * KP + 4 * ks + lg];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int q = j + kw;
-          bb[d][j] = in_s[(((2 * rp + d + kh) * 2 + (q & 1)) * HP + pcol + (q >> 1)) * S16 + ci];
-        }
+        for (int d = 0; d < 2; ++d)
 #pragma unroll
-      for (int d = 0; d < 2; ++d)
+          for (int j = 0; j < 2; ++j) {
+            const int q = j + kw;
+            bb[k4][d][j] = in_s[(((2 * rp + d + kh) * 2 + (q & 1)) * HP + pcol + (q >> 1)) * S16 + ci];
+          }
+      }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int k4 = 0; k4 < 4; ++k4)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) acc[i][d][j] = mfma16(a[i], bb[d][j], acc[i][d][j]);
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i][d][j] = mfma16(a[k4][i], bb[k4][d][j], acc[i][d][j]);
     }
   }
   STAMP(2);
