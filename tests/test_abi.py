@@ -50,3 +50,26 @@ def test_ops_refuse_cpu_tensors():
         ops.gemm(torch.zeros(2, 2), torch.zeros(2, 2))
     with pytest.raises(ops.GdmError):
         ops.adam_step(torch.zeros(4), torch.zeros(4), torch.zeros(4), torch.zeros(4), 1, 1e-3, 0.9, 0.999, 1e-8)
+
+
+def test_build_stamp_covers_flags_and_compiler(monkeypatch):
+    """build.py rebuilds every object when the flag set (or the compiler) differs from the one recorded beside the
+    objects, and an experiment flag set marks the library (gdm_build_flavor)."""
+    import importlib
+    from gan_des_midi_music_gen_amd import build
+    shipped = build._flags_stamp(build._hipcc())
+    assert "--offload-arch=gfx950" in shipped and "GDM_EXPERIMENT_BUILD" not in shipped
+    assert open(build.STAMP).read() == shipped, "the in-tree objects were built with the shipped flags"
+    monkeypatch.setenv("GDM_HIPCC_FLAGS", "-DGDM_STAMPS")
+    monkeypatch.setenv("GDM_BUILD_TAG", "stamp_test")
+    variant = importlib.reload(build)
+    try:
+        assert "-DGDM_STAMPS" in variant._flags_stamp(variant._hipcc()) and "-DGDM_EXPERIMENT_BUILD=1" in variant.FLAGS
+        assert variant.LIB.endswith("libgdm_hip_stamp_test.so") and variant.OBJ.endswith("_obj_stamp_test")
+        assert variant._flags_stamp(variant._hipcc()) != shipped
+    finally:
+        monkeypatch.delenv("GDM_HIPCC_FLAGS")
+        monkeypatch.delenv("GDM_BUILD_TAG")
+        importlib.reload(build)
+    from gan_des_midi_music_gen_amd import _lib
+    assert _lib.load().gdm_build_flavor() == 0

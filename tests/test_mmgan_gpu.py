@@ -367,3 +367,34 @@ def test_training_loop_entry_point(tmp_path):
     fresh.load_state_dict(sd, strict=True)
     # 2 epochs x 3 iterations x 2 generator forwards per iteration
     assert int(sd["generator1.gen.0.1.num_batches_tracked"]) == 12
+
+
+def test_replay_follows_the_lr_schedule():
+    """After capture(), StepLR changes trainer.lr on the host; replay() refreshes the device hyper-parameter record before
+    launching, so replayed and eager iterations stay bit-identical across a decay (network_tests.py:257-258, 328-329)."""
+    b = 16
+    outs = []
+    for mode in ("eager", "graph"):
+        mm = _mm(21).to(DEV)
+        tr = MmganTrainer(mm, lr=0.01, compute_dtype="bf16")
+        sched = StepLR(tr, step_size=2, gamma=0.1)
+        d = synthetic.mmgan_inputs(b, 50, seed=78, device=DEV)
+        args = (d["piano_roll"], d["durations"], d["beats"], d["noise1"], d["noise2"], d["fake_a"], d["fake_b"])
+        if mode == "graph":
+            tr.capture(*args, d["g1_in_a"], d["g1_in_b"])      # 2 iterations at lr 0.01
+        else:
+            for _ in range(2):
+                tr.step(*args, g1_in_a=d["g1_in_a"], g1_in_b=d["g1_in_b"])
+        lrs = []
+        for epoch in range(3):
+            sched.step()
+            lrs.append(tr.lr)
+            if mode == "graph":
+                tr.replay()
+            else:
+                tr.step(*args, g1_in_a=d["g1_in_a"], g1_in_b=d["g1_in_b"])
+        torch.cuda.synchronize()
+        assert lrs == [0.01, 0.01 * 0.1, 0.01 * 0.1]
+        outs.append((tr.disc_loss_value(), mm.discriminator.fc.weight.detach().clone(),
+                     mm.discriminator.conv1.weight.detach().clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
