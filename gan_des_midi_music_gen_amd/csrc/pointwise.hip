@@ -539,6 +539,36 @@ extern "C" int gdm_bn_act_fwd(const float* y, int rows, int channels, const floa
   return GDM_OK;
 }
 
+extern "C" int gdm_bn_finalize(const float* ws, int chunks, int rows, int channels, float momentum, float eps,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean,
+                               float* save_invstd, void* stream) {
+  GDM_REQUIRE(ws && save_mean && save_invstd && chunks > 0 && rows > 1 && channels > 0, "gdm_bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize, dim3((channels + 63) / 64), dim3(1024), 0, (hipStream_t)stream, ws, chunks, rows,
+                     channels, momentum, eps, running_mean, running_var, num_batches_tracked, save_mean, save_invstd);
+  GDM_LAUNCH_OK("gdm_bn_finalize");
+  return GDM_OK;
+}
+
+extern "C" int gdm_bn_stats(const float* y, int rows, int channels, float* running_mean, float* running_var,
+                            int64_t* num_batches_tracked, float momentum, float eps, float* save_mean,
+                            float* save_invstd, void* workspace, size_t workspace_bytes, void* stream) {
+  GDM_REQUIRE(y && save_mean && save_invstd && rows > 1 && channels > 0, "gdm_bn_stats: bad arguments");
+  if (!workspace || workspace_bytes < gdm_bn_workspace_bytes(rows, channels)) {
+    gdm_set_error("gdm_bn_stats: workspace too small");
+    return GDM_EWORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int C = channels, chunks = row_chunks(rows), chunk_rows = (rows + chunks - 1) / chunks;
+  int cw = 64;
+  while (cw / 2 >= C && cw > 1) cw /= 2;
+  hipLaunchKernelGGL(bn_partial_stats, dim3((C + 63) / 64, chunks), dim3(256), 0, s, y, rows, C, chunk_rows, cw,
+                     (float*)workspace);
+  hipLaunchKernelGGL(bn_finalize, dim3((C + 63) / 64), dim3(1024), 0, s, (const float*)workspace, chunks, rows, C,
+                     momentum, eps, running_mean, running_var, num_batches_tracked, save_mean, save_invstd);
+  GDM_LAUNCH_OK("gdm_bn_stats");
+  return GDM_OK;
+}
+
 extern "C" int gdm_bn_act_bwd(const void* dout, const void* out, int out_dtype, const float* y, int rows, int channels,
                               const float* gamma, const float* save_mean, const float* save_invstd, int act,
                               float* dy, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,

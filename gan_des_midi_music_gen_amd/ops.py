@@ -200,6 +200,66 @@ def bn_act_fwd(y, gamma, beta, running_mean, running_var, nbt, *, act, out_dtype
     return out, mean, invstd
 
 
+def bn_stats(y, running_mean, running_var, nbt, *, momentum=0.1, eps=1e-5):
+    """Training-mode batch statistics of y (rows, C) fp32 -> (mean, invstd); running statistics updated."""
+    _need_gpu(y, running_mean, running_var, nbt)
+    assert y.dim() == 2 and y.dtype == torch.float32 and y.is_contiguous()
+    rows, c = y.shape
+    mean = torch.empty(c, dtype=torch.float32, device=y.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=y.device)
+    nb = _lib.load().gdm_bn_workspace_bytes(rows, c)
+    ws = workspace(nb, y.device)
+    _call("gdm_bn_stats", _p(y), rows, c, _p(running_mean), _p(running_var), _p(nbt), float(momentum), float(eps),
+          _p(mean), _p(invstd), _p(ws), nb, _stream())
+    return mean, invstd
+
+
+def bn_finalize(partials, chunks, rows, c, running_mean, running_var, nbt, *, momentum=0.1, eps=1e-5):
+    """Merge (chunks, c, 3) Welford partials -> (mean, invstd); running statistics updated."""
+    _need_gpu(partials, running_mean, running_var, nbt)
+    assert partials.dtype == torch.float32 and partials.is_contiguous() and partials.numel() >= chunks * c * 3
+    mean = torch.empty(c, dtype=torch.float32, device=partials.device)
+    invstd = torch.empty(c, dtype=torch.float32, device=partials.device)
+    _call("gdm_bn_finalize", _p(partials), int(chunks), int(rows), int(c), float(momentum), float(eps), _p(running_mean),
+          _p(running_var), _p(nbt), _p(mean), _p(invstd), _stream())
+    return mean, invstd
+
+
+def simnn_gen_pack(w2, w3, out=None):
+    """bf16 parity-class GEMM images of the generator's conv2 / conv3 weights (rebuild when they change)."""
+    _need_gpu(w2, w3, out)
+    assert w2.shape == (128, 64, 4, 4) and w3.shape == (64, 32, 4, 4) and w2.is_contiguous() and w3.is_contiguous()
+    assert w2.dtype == torch.float32 and w3.dtype == torch.float32
+    nb = _lib.load().gdm_simnn_gen_pack_bytes()
+    pack = out if out is not None else torch.empty(nb, dtype=torch.uint8, device=w2.device)
+    assert pack.numel() == nb
+    _call("gdm_simnn_gen_pack", _p(w2), _p(w3), _p(pack), _stream())
+    return pack
+
+
+def simnn_gen_convt_bn(layer, yin, mean, invstd, gamma, beta, b, pack):
+    """Fused BN+ReLU-on-load + ConvTranspose2d(k4,s2,p1) of generator layer 2 or 3.
+    Returns (yout (B*OH*OW, Cout) fp32 raw, partials (chunks, Cout, 3), chunks)."""
+    _need_gpu(yin, mean, invstd, gamma, beta, pack)
+    cin, cout, ih = (128, 64, 4) if layer == 2 else (64, 32, 8)
+    assert yin.shape == (b * ih * ih, cin) and yin.dtype == torch.float32 and yin.is_contiguous()
+    chunks = _lib.load().gdm_simnn_gen_convt_chunks(layer, b)
+    yout = torch.empty((b * 4 * ih * ih, cout), dtype=torch.float32, device=yin.device)
+    partials = torch.empty((chunks, cout, 3), dtype=torch.float32, device=yin.device)
+    _call("gdm_simnn_gen_convt_bn", layer, _p(yin), _p(mean), _p(invstd), _p(gamma), _p(beta), b, _p(pack), _p(yout),
+          _p(partials), _stream())
+    return yout, partials, chunks
+
+
+def simnn_gen_last(yin, mean, invstd, gamma, beta, w4, b):
+    """BN+ReLU on load, ConvTranspose2d(32->1,k5), sigmoid: y3 (B*256, 32) -> (B, 1, 20, 20)."""
+    _need_gpu(yin, mean, invstd, gamma, beta, w4)
+    assert yin.shape == (b * 256, 32) and yin.is_contiguous() and w4.shape == (32, 1, 5, 5) and w4.is_contiguous()
+    out = torch.empty((b, 1, 20, 20), dtype=torch.float32, device=yin.device)
+    _call("gdm_simnn_gen_last", _p(yin), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(w4), b, _p(out), _stream())
+    return out
+
+
 def bn_act_bwd(dout, out, y, gamma, mean, invstd, *, act):
     _need_gpu(dout, out, y, gamma, mean, invstd)
     rows, c = y.shape

@@ -331,7 +331,8 @@ class SimnnTrainer(_TrainerBase):
             if side:
                 side[0].wait_stream(main)
             with torch.cuda.stream(side[0] if side else main):
-                generated, gsaved = Fn.simnn_gen_forward(noise, ws, bns, self.gen.training, dt, cache=self._tm_cache)
+                generated, gsaved = Fn.simnn_gen_forward(noise, ws, bns, self.gen.training, dt, cache=self._tm_cache,
+                                                           need_backward=False)
                 keep.append(gsaved)
             self.last_generated = generated
             return generated
@@ -434,7 +435,8 @@ class SimnnTrainer(_TrainerBase):
         if side:
             side[0].wait_stream(main)
         with torch.cuda.stream(side[0] if side else main):
-            generated, gsaved = Fn.simnn_gen_forward(noise, ws, bns, self.gen.training, dt, cache=self._tm_cache)
+            generated, gsaved = Fn.simnn_gen_forward(noise, ws, bns, self.gen.training, dt, cache=self._tm_cache,
+                                                           need_backward=False)
             keep.append(gsaved)
         self.last_generated = generated
         ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))

@@ -93,6 +93,33 @@ int gdm_bn_act_fwd(const float* y, int rows, int channels, const float* gamma, c
 int gdm_bn_act_bwd(const void* dout, const void* out, int out_dtype, const float* y, int rows, int channels,
                    const float* gamma, const float* save_mean, const float* save_invstd, int act, float* dy,
                    float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+/* The statistics half of gdm_bn_act_fwd alone (training mode): per-channel batch mean / 1/sqrt(var+eps) into save_*,
+ * running statistics and num_batches_tracked updated; the consumer applies the normalisation itself (the fused generator
+ * kernels below do it while they load their input).  gdm_bn_finalize merges `chunks` x channels (n, mean, M2) partials
+ * laid out [chunk][channel][3] -- what gdm_simnn_gen_convt_bn leaves -- in chunk order.                              */
+int gdm_bn_stats(const float* y, int rows, int channels, float* running_mean, float* running_var,
+                 int64_t* num_batches_tracked, float momentum, float eps, float* save_mean, float* save_invstd,
+                 void* workspace, size_t workspace_bytes, void* stream);
+int gdm_bn_finalize(const float* ws, int chunks, int rows, int channels, float momentum, float eps, float* running_mean,
+                    float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd, void* stream);
+
+/* ---- model 1 generator, layers 2..4 fused (GAN_DES/SIMNN.py:105-110; forward only, training-mode BatchNorm, the
+ * reference's default geometry: 128 -> 64 -> 32 -> 1 channels, 4x4 -> 8x8 -> 16x16 -> 20x20).  Activations are
+ * channels-last fp32 row matrices (B*H*W, C) holding the PRE-normalisation convolution outputs.
+ * gdm_simnn_gen_pack: conv2.weight (128,64,4,4), conv3.weight (64,32,4,4) -> bf16 parity-class GEMM images.
+ * gdm_simnn_gen_convt_bn(layer 2|3): BatchNorm(mean, invstd, gamma, beta) + ReLU applied to yin while it is staged,
+ *   ConvTranspose2d(k4,s2,p1) as four 2x2-tap implicit GEMMs on bf16 MFMA -> yout, plus one (n, mean, M2) partial per
+ *   workgroup and output channel in ws_partials (gdm_simnn_gen_convt_chunks(layer, B) x Cout x 3 floats) for
+ *   gdm_bn_finalize.
+ * gdm_simnn_gen_last: BatchNorm + ReLU on load, ConvTranspose2d(32 -> 1, k5, s1, p0), sigmoid -> out (B, 20*20).     */
+size_t gdm_simnn_gen_pack_bytes(void);
+int gdm_simnn_gen_pack(const float* w2, const float* w3, void* pack, void* stream);
+int gdm_simnn_gen_convt_chunks(int layer, int B);
+int gdm_simnn_gen_convt_bn(int layer, const float* yin, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, int B, const void* pack, float* yout, float* ws_partials, void* stream);
+int gdm_simnn_gen_last(const float* yin, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                       const float* w4, int B, float* out, void* stream);
+
 
 /* ---- elementwise helpers ---------------------------------------------------------------------------------------*/
 /* out = act(x + bias[col]) and its backward dx = dout * act'(out); (rows, cols) row-major. */

@@ -448,3 +448,38 @@ def test_workspace_buffers_seen_by_a_graph_are_never_released():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want) and big.isfinite().all() and len(junk) == 8
+
+
+@pytest.mark.parametrize("b", [2, 5, 13, 256])
+def test_fused_generator_forward_matches_the_layerwise_path_and_the_oracle(b):
+    """The trainers' forward-only generator (csrc/simnn_gen.hip: BatchNorm+ReLU applied while the next transposed
+    convolution stages its input, per-workgroup BatchNorm partials) against (a) the layer-by-layer GEMM + col2im +
+    batch-norm path on the same bf16 operands and (b) the fp32 CPU oracle, incl. batches that do not fill the last
+    workgroup's sample group."""
+    torch.manual_seed(31)
+    ref = osn.Generator().apply(osn.weights_init)
+    gens = []
+    for _ in range(2):
+        g = SIMNN.Generator()
+        g.load_state_dict(ref.state_dict())
+        gens.append(g.to(DEV).train())
+    noise = torch.randn(b, 100, 1, 1, generator=torch.Generator().manual_seed(b))
+    outs = []
+    for g, need_bwd in zip(gens, (False, True)):
+        ws = [g.conv1.weight.detach(), g.conv2.weight.detach(), g.conv3.weight.detach(), g.conv4.weight.detach()]
+        bns = [(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.num_batches_tracked)
+               for bn in (g.batch_norm1, g.batch_norm2, g.batch_norm3)]
+        img, saved = Fn.simnn_gen_forward(noise.to(DEV), ws, bns, True, Fn.BF16, cache={}, need_backward=need_bwd)
+        assert (saved is None) == (not need_bwd)
+        outs.append(img)
+    want = ref.train()(noise)
+    assert outs[0].shape == (b, 1, 20, 20)
+    _close(outs[0], outs[1], 2e-4, "fused vs layer-wise generator")
+    _close(outs[0], want, 1e-3, "fused generator vs oracle")
+    for k in ("batch_norm1", "batch_norm2", "batch_norm3"):
+        fa, fb, fr = getattr(gens[0], k), getattr(gens[1], k), getattr(ref, k)
+        assert int(fa.num_batches_tracked) == int(fb.num_batches_tracked) == 1
+        _close(fa.running_mean, fb.running_mean, 1e-3, k + " running_mean vs layer-wise")
+        _close(fa.running_var, fb.running_var, 1e-3, k + " running_var vs layer-wise")
+        _close(fa.running_mean, fr.running_mean, 1e-2, k + " running_mean vs oracle")      # bf16 operands, tiny batches
+        _close(fa.running_var, fr.running_var, 1e-2, k + " running_var vs oracle")

@@ -35,6 +35,8 @@ def fake_gen(noise, ws, bns, training, dt, **kw):
     return cache["o"]
 Fn.simnn_gen_forward = fake_gen
 print(f"graph, overlap, no G fwd  : {timed(build(True)):8.1f} us/step")
+cache.clear()
+print(f"graph, pipelined, no G fwd: {timed(build(True, True)):8.1f} us/step")
 Fn.simnn_gen_forward = orig_gen
 orig_bw = ops.simnn_conv2_bwd_weight
 ops.simnn_conv2_bwd_weight = lambda dp2, code2, p1, out=None: out
