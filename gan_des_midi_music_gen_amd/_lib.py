@@ -35,7 +35,8 @@ SIGNATURES = {
     "gdm_bn_stats": (_I, [_P, _I, _I, _P, _P, _P, _F, _F, _P, _P, _P, _Z, _P]),
     "gdm_bn_finalize": (_I, [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "gdm_simnn_gen_pack_bytes": (_Z, []),
-    "gdm_simnn_gen_pack": (_I, [_P, _P, _P, _P]),
+    "gdm_simnn_gen_pack": (_I, [_P, _I, _P, _P, _P, _P]),
+    "gdm_simnn_gen_first": (_I, [_P, _I, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     "gdm_simnn_gen_convt_chunks": (_I, [_I, _I]),
     "gdm_simnn_gen_convt_bn": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "gdm_simnn_gen_last": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P]),

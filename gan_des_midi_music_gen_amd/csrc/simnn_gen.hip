@@ -29,11 +29,135 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, __bf16* __
   dst[i] = (__bf16)w[((ci * COUT + co) * 4 + kh) * 4 + kw];              // torch ConvTranspose2d weight (Cin, Cout, KH, KW)
 }
 constexpr int GP_W2 = 4 * 64 * 4 * 128, GP_W3 = 4 * 32 * 4 * 64;          // elements
-__global__ __launch_bounds__(256) void gen_pack_kernel(const float* __restrict__ w2, const float* __restrict__ w3,
+constexpr int L1_K = 128, GP_W1 = 16 * 128 * L1_K;                        // conv1: [n = pos*128 + co][k = ci, zero padded]
+__global__ __launch_bounds__(256) void gen_pack_kernel(const float* __restrict__ w1, int noise_dim,
+                                                       const float* __restrict__ w2, const float* __restrict__ w3,
                                                        __bf16* __restrict__ pack) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < GP_W2) pack_one<128, 64>(w2, pack, i);
   else if (i < GP_W2 + GP_W3) pack_one<64, 32>(w3, pack + GP_W2, i - GP_W2);
+  else if (i < GP_W2 + GP_W3 + GP_W1) {
+    const int j = i - GP_W2 - GP_W3, k = j % L1_K, n = j / L1_K, co = n % 128, pos = n / 128;
+    pack[i] = (__bf16)(k < noise_dim ? w1[((size_t)k * 128 + co) * 16 + pos] : 0.f);   // (Cin, 128, 4, 4)
+  }
+}
+
+// ---- first layer: ConvT(noise_dim -> 128, k4, s1, p0) on a 1x1 input = a (B, noise_dim) x (noise_dim, 16*128) product,
+// with its BatchNorm statistics: a 512-thread workgroup owns 16 channels at all 16 positions for the WHOLE batch
+// (B <= 256), so the channel statistics are exact two-pass sums inside the workgroup and no partial / finalize launch
+// follows.  M = n (weights, A), N = b (noise, B operand), K = noise_dim padded to 128.
+__global__ __launch_bounds__(512) void gen_l1_kernel(const float* __restrict__ noise, int B, int noise_dim,
+                                                     const __bf16* __restrict__ w1p, float* __restrict__ y1,
+                                                     float momentum, float eps, float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var, int64_t* __restrict__ nbt,
+                                                     float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  constexpr int SK = L1_K + 8;                                             // padded LDS row (see convt_s2_bn_kernel)
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+  __bf16* x_s = (__bf16*)dyn_smem;                                         // [256 b][SK]
+  __bf16* w_s = x_s + 256 * SK;                                            // [16 pos][16 co][SK]
+  __shared__ float red[8][16], cmean[16];
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
+  const int c0 = blockIdx.x * 16;
+  // stage: weights of this channel block (256 rows x 128 k, 16-byte chunks), noise rows converted to bf16 (zero padded)
+  {
+    f32x4 wr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = t + 512 * k, row = i / (L1_K / 8), c8 = i % (L1_K / 8), pos = row >> 4, co = row & 15;
+      wr[k] = *(const f32x4*)&w1p[((size_t)(pos * 128 + c0 + co)) * L1_K + 8 * c8];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = t + 512 * k, row = i / (L1_K / 8), c8 = i % (L1_K / 8);
+      *(f32x4*)&w_s[row * SK + 8 * c8] = wr[k];
+    }
+  }
+  {   // noise: 4 values per thread and step, all 16 steps' loads in flight before the first conversion
+    const bool vec = (noise_dim % 4 == 0) && (((uintptr_t)noise & 15) == 0);
+    f32x4 xr[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = t + 512 * k, b = i / (L1_K / 4), k4 = 4 * (i % (L1_K / 4));
+      xr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (b < B && k4 < noise_dim) {
+        const float* src = noise + (size_t)b * noise_dim + k4;
+        if (vec) xr[k] = *(const f32x4*)src;
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xr[k][e] = (k4 + e < noise_dim) ? src[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = t + 512 * k, b = i / (L1_K / 4), k4 = 4 * (i % (L1_K / 4));
+      bf16x4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = (__bf16)xr[k][e];
+      *(bf16x4*)&x_s[b * SK + k4] = h;
+    }
+  }
+  __syncthreads();
+  f32x4 acc[2][16];                                                        // [pos tile of this wave][batch tile]
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int bt = 0; bt < 16; ++bt) acc[p][bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < L1_K / 32; ++ks) {
+    bf16x8 af[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) af[p] = *(const bf16x8*)&w_s[((2 * wv + p) * 16 + lr) * SK + ks * 32 + 8 * lg];
+#pragma unroll
+    for (int bt = 0; bt < 16; ++bt) {
+      const bf16x8 bf = *(const bf16x8*)&x_s[(bt * 16 + lr) * SK + ks * 32 + 8 * lg];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) acc[p][bt] = mfma16(af[p], bf, acc[p][bt]);
+    }
+  }
+  // C: col (lr) = b within the batch tile, rows 4*lg + r = channel c0 + 4*lg + r, at position 2*wv + p
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int bt = 0; bt < 16; ++bt) {
+      const int b = bt * 16 + lr;
+      if (b < B) *(f32x4*)&y1[((size_t)b * 16 + 2 * wv + p) * 128 + c0 + 4 * lg] = acc[p][bt];
+    }
+  auto reduce = [&](auto value) {                                          // per channel r of this lane's group -> red[wv][4lg+r]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sum = 0.f;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int bt = 0; bt < 16; ++bt) sum += (bt * 16 + lr < B) ? value(acc[p][bt][r], 4 * lg + r) : 0.f;
+      sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
+      sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 8, 64);
+      if (lr == 0) red[wv][4 * lg + r] = sum;
+    }
+  };
+  const float n = (float)B * 16.f;
+  reduce([&](float v, int) { return v; });
+  __syncthreads();
+  if (t < 16) {
+    float sum = 0.f;
+    for (int w = 0; w < 8; ++w) sum += red[w][t];
+    cmean[t] = sum / n;
+  }
+  __syncthreads();
+  reduce([&](float v, int c) { const float d = v - cmean[c]; return d * d; });
+  __syncthreads();
+  if (t < 16) {
+    float m2 = 0.f;
+    for (int w = 0; w < 8; ++w) m2 += red[w][t];
+    const int c = c0 + t;
+    save_mean[c] = cmean[t];
+    save_invstd[c] = 1.0f / sqrtf(m2 / n + eps);
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * cmean[t];
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (m2 / fmaxf(n - 1.f, 1.f));
+    }
+  }
+  if (blockIdx.x == 0 && t == 0 && nbt) nbt[0] += 1;
 }
 
 // ---- ConvT k4 s2 p1 with BatchNorm+ReLU applied to its input on load ----------------------------------------------------
@@ -241,13 +365,30 @@ int launch_convt_s2(const float* yin, const float* mean, const float* invstd, co
 
 }  // namespace
 
-extern "C" size_t gdm_simnn_gen_pack_bytes(void) { return (size_t)(GP_W2 + GP_W3) * 2; }
+extern "C" size_t gdm_simnn_gen_pack_bytes(void) { return (size_t)(GP_W2 + GP_W3 + GP_W1) * 2; }
 
-extern "C" int gdm_simnn_gen_pack(const float* w2, const float* w3, void* pack, void* stream) {
-  GDM_REQUIRE(w2 && w3 && pack && ((uintptr_t)pack & 15) == 0, "gdm_simnn_gen_pack: bad arguments");
-  hipLaunchKernelGGL(gen_pack_kernel, dim3((GP_W2 + GP_W3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w2, w3,
-                     (__bf16*)pack);
+extern "C" int gdm_simnn_gen_pack(const float* w1, int noise_dim, const float* w2, const float* w3, void* pack,
+                                  void* stream) {
+  GDM_REQUIRE(w1 && w2 && w3 && pack && ((uintptr_t)pack & 15) == 0 && noise_dim >= 1 && noise_dim <= L1_K,
+              "gdm_simnn_gen_pack: bad arguments (noise_dim <= %d)", L1_K);
+  hipLaunchKernelGGL(gen_pack_kernel, dim3((GP_W2 + GP_W3 + GP_W1 + 255) / 256), dim3(256), 0, (hipStream_t)stream, w1,
+                     noise_dim, w2, w3, (__bf16*)pack);
   GDM_LAUNCH_OK("gdm_simnn_gen_pack");
+  return GDM_OK;
+}
+
+extern "C" int gdm_simnn_gen_first(const float* noise, int B, int noise_dim, const void* pack, float* y1, float momentum,
+                                   float eps, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                   float* save_mean, float* save_invstd, void* stream) {
+  GDM_REQUIRE(noise && pack && y1 && save_mean && save_invstd, "gdm_simnn_gen_first: null pointer");
+  GDM_REQUIRE(B > 1 && B <= 256 && noise_dim >= 1 && noise_dim <= L1_K && ((uintptr_t)y1 & 15) == 0,
+              "gdm_simnn_gen_first: batch %d outside 2..256 (the workgroup owns the whole batch) or noise_dim > %d", B, L1_K);
+  const size_t sm = (size_t)2 * 256 * (L1_K + 8) * 2;
+  allow_dyn_lds(gen_l1_kernel, sm);
+  hipLaunchKernelGGL(gen_l1_kernel, dim3(8), dim3(512), sm, (hipStream_t)stream, noise, B, noise_dim,
+                     (const __bf16*)pack + GP_W2 + GP_W3, y1, momentum, eps, running_mean, running_var,
+                     num_batches_tracked, save_mean, save_invstd);
+  GDM_LAUNCH_OK("gdm_simnn_gen_first");
   return GDM_OK;
 }
 

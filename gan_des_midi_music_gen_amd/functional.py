@@ -224,13 +224,14 @@ def _gen_pack(ws, cache):
     """bf16 GEMM images of conv2 / conv3 for the fused generator kernels, cached per weight version like
     _tap_major_weight (refreshed in place when a weight changed; the generators are frozen during training)."""
     key = "gen_pack"
-    ver = (ws[1].data_ptr(), ws[1]._version, ws[2].data_ptr(), ws[2]._version)
+    ver = tuple(v for w in ws[:3] for v in (w.data_ptr(), w._version))
     hit = cache.get(key) if cache is not None else None
     if hit is not None and hit[0] == ver:
         return hit[1]
     if hit is None and cache is not None and torch.cuda.is_current_stream_capturing():
         raise ops.GdmError("the generator's weights were first seen inside a graph capture: run one eager step first")
-    pack = ops.simnn_gen_pack(ws[1].contiguous(), ws[2].contiguous(), out=None if hit is None else hit[1])
+    pack = ops.simnn_gen_pack(ws[0].contiguous(), ws[1].contiguous(), ws[2].contiguous(),
+                              out=None if hit is None else hit[1])
     if cache is not None:
         cache[key] = (ver, pack)
     return pack
@@ -238,14 +239,17 @@ def _gen_pack(ws, cache):
 
 def simnn_gen_forward_fused(noise, ws, bns, dt, cache=None):
     """The training loop's generator forward (train-mode BatchNorm, reference geometry, forward only): layer 1 as a
-    GEMM + batch statistics, layers 2..4 as three fused kernels that normalise their input while they stage it
-    (csrc/simnn_gen.hip).  7 launches instead of 20; nothing is saved for a backward."""
+    GEMM with its batch statistics in the same launch, layers 2..4 as three fused kernels that normalise their input
+    while they stage it (csrc/simnn_gen.hip).  6 launches instead of 20; nothing is saved for a backward."""
     b = noise.shape[0]
     x = _f32c(noise).view(b, -1)
     pack = _gen_pack(ws, cache)
-    y1, _, _ = convT_forward(x, ws[0], b, 1, 1, 1, 0, dt, cache=cache, slot=0)              # (B*16, 128): no scatter pass
     g1, be1, rm1, rv1, nbt1 = bns[0]
-    mean, invstd = ops.bn_stats(y1, rm1, rv1, nbt1)
+    if b <= 256:          # layer 1 and its exact batch statistics in one launch (a workgroup owns the whole batch)
+        y1, mean, invstd = ops.simnn_gen_first(x, pack, rm1, rv1, nbt1)
+    else:
+        y1, _, _ = convT_forward(x, ws[0], b, 1, 1, 1, 0, dt, cache=cache, slot=0)          # (B*16, 128): no scatter pass
+        mean, invstd = ops.bn_stats(y1, rm1, rv1, nbt1)
     y2, part, chunks = ops.simnn_gen_convt_bn(2, y1, mean, invstd, g1, be1, b, pack)
     g2, be2, rm2, rv2, nbt2 = bns[1]
     mean, invstd = ops.bn_finalize(part, chunks, b * 64, 64, rm2, rv2, nbt2)
@@ -257,6 +261,7 @@ def simnn_gen_forward_fused(noise, ws, bns, dt, cache=None):
 
 def _gen_fused_ok(noise, ws, training, dt, need_backward):
     return (training and not need_backward and dt == BF16 and noise.shape[0] > 1 and tuple(ws[0].shape[1:]) == (128, 4, 4)
+            and ws[0].shape[0] <= 128
             and tuple(ws[1].shape) == (128, 64, 4, 4) and tuple(ws[2].shape) == (64, 32, 4, 4)
             and tuple(ws[3].shape) == (32, 1, 5, 5))
 

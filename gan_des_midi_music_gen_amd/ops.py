@@ -225,16 +225,31 @@ def bn_finalize(partials, chunks, rows, c, running_mean, running_var, nbt, *, mo
     return mean, invstd
 
 
-def simnn_gen_pack(w2, w3, out=None):
-    """bf16 parity-class GEMM images of the generator's conv2 / conv3 weights (rebuild when they change)."""
-    _need_gpu(w2, w3, out)
-    assert w2.shape == (128, 64, 4, 4) and w3.shape == (64, 32, 4, 4) and w2.is_contiguous() and w3.is_contiguous()
-    assert w2.dtype == torch.float32 and w3.dtype == torch.float32
+def simnn_gen_pack(w1, w2, w3, out=None):
+    """bf16 GEMM images of the generator's conv1 / conv2 / conv3 weights (rebuild when they change)."""
+    _need_gpu(w1, w2, w3, out)
+    assert w1.dim() == 4 and w1.shape[1:] == (128, 4, 4) and w1.shape[0] <= 128
+    assert w2.shape == (128, 64, 4, 4) and w3.shape == (64, 32, 4, 4)
+    for w in (w1, w2, w3):
+        assert w.is_contiguous() and w.dtype == torch.float32
     nb = _lib.load().gdm_simnn_gen_pack_bytes()
     pack = out if out is not None else torch.empty(nb, dtype=torch.uint8, device=w2.device)
     assert pack.numel() == nb
-    _call("gdm_simnn_gen_pack", _p(w2), _p(w3), _p(pack), _stream())
+    _call("gdm_simnn_gen_pack", _p(w1), int(w1.shape[0]), _p(w2), _p(w3), _p(pack), _stream())
     return pack
+
+
+def simnn_gen_first(noise2d, pack, running_mean, running_var, nbt, *, momentum=0.1, eps=1e-5):
+    """Generator layer 1 + its batch statistics in one launch: noise (B, noise_dim) -> (y1 (B*16, 128), mean, invstd)."""
+    _need_gpu(noise2d, pack, running_mean, running_var, nbt)
+    b, nd = noise2d.shape
+    assert noise2d.dtype == torch.float32 and noise2d.is_contiguous() and 2 <= b <= 256 and nd <= 128
+    y1 = torch.empty((b * 16, 128), dtype=torch.float32, device=noise2d.device)
+    mean = torch.empty(128, dtype=torch.float32, device=noise2d.device)
+    invstd = torch.empty(128, dtype=torch.float32, device=noise2d.device)
+    _call("gdm_simnn_gen_first", _p(noise2d), b, nd, _p(pack), _p(y1), float(momentum), float(eps), _p(running_mean),
+          _p(running_var), _p(nbt), _p(mean), _p(invstd), _stream())
+    return y1, mean, invstd
 
 
 def simnn_gen_convt_bn(layer, yin, mean, invstd, gamma, beta, b, pack):

@@ -106,14 +106,21 @@ int gdm_bn_finalize(const float* ws, int chunks, int rows, int channels, float m
 /* ---- model 1 generator, layers 2..4 fused (GAN_DES/SIMNN.py:105-110; forward only, training-mode BatchNorm, the
  * reference's default geometry: 128 -> 64 -> 32 -> 1 channels, 4x4 -> 8x8 -> 16x16 -> 20x20).  Activations are
  * channels-last fp32 row matrices (B*H*W, C) holding the PRE-normalisation convolution outputs.
- * gdm_simnn_gen_pack: conv2.weight (128,64,4,4), conv3.weight (64,32,4,4) -> bf16 parity-class GEMM images.
+ * gdm_simnn_gen_pack: conv1.weight (noise_dim,128,4,4), conv2.weight (128,64,4,4), conv3.weight (64,32,4,4) -> bf16
+ *   GEMM images (conv1: [pos*128+co][k], conv2/3: parity classes).
+ * gdm_simnn_gen_first: ConvTranspose2d(noise_dim -> 128, k4) on the 1x1 noise = a GEMM, y1 (B*16, 128), plus the exact
+ *   training-mode BatchNorm statistics of its 128 channels (save_mean / save_invstd, running statistics,
+ *   num_batches_tracked) in the same launch: a workgroup owns 16 channels for the whole batch (2 <= B <= 256).
  * gdm_simnn_gen_convt_bn(layer 2|3): BatchNorm(mean, invstd, gamma, beta) + ReLU applied to yin while it is staged,
  *   ConvTranspose2d(k4,s2,p1) as four 2x2-tap implicit GEMMs on bf16 MFMA -> yout, plus one (n, mean, M2) partial per
  *   workgroup and output channel in ws_partials (gdm_simnn_gen_convt_chunks(layer, B) x Cout x 3 floats) for
  *   gdm_bn_finalize.
  * gdm_simnn_gen_last: BatchNorm + ReLU on load, ConvTranspose2d(32 -> 1, k5, s1, p0), sigmoid -> out (B, 20*20).     */
 size_t gdm_simnn_gen_pack_bytes(void);
-int gdm_simnn_gen_pack(const float* w2, const float* w3, void* pack, void* stream);
+int gdm_simnn_gen_pack(const float* w1, int noise_dim, const float* w2, const float* w3, void* pack, void* stream);
+int gdm_simnn_gen_first(const float* noise, int B, int noise_dim, const void* pack, float* y1, float momentum, float eps,
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean,
+                        float* save_invstd, void* stream);
 int gdm_simnn_gen_convt_chunks(int layer, int B);
 int gdm_simnn_gen_convt_bn(int layer, const float* yin, const float* mean, const float* invstd, const float* gamma,
                            const float* beta, int B, const void* pack, float* yout, float* ws_partials, void* stream);
