@@ -15,8 +15,12 @@ namespace {
 
 constexpr int LB_M = 256, LB_N = 32, LB_KT = 32, LB_LD = LB_KT + 8;
 
-template <bool VEC>
-__global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* x, const float* __restrict__ w,
+// GP = groups in flight per workgroup (1 or 2): with GP = 2 the workgroup has 512 threads, waves 0-3 run group g and waves
+// 4-7 group g+1 through the same barriers (the launch is a latency chain -- staging, MFMA, two reduction rounds, stores --
+// so two groups one after the other cost twice the launch, side by side barely more than one); the running statistics
+// still take the groups' updates in order, applied by the first group's threads once both batches' statistics are in LDS.
+template <bool VEC, int GP>
+__global__ __launch_bounds__(256 * GP) void linear_bn_act_kernel(const float* x, const float* __restrict__ w,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
@@ -28,13 +32,17 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* x, cons
                                                             float* __restrict__ save_mean,
                                                             float* __restrict__ save_invstd, int groups,
                                                             int stat_repeats) {
-  __shared__ __attribute__((aligned(16))) __bf16 As[2][LB_M * LB_LD];     // [hi | lo]
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][LB_N * LB_LD];
-  __shared__ float colred[4][LB_N];
-  __shared__ float colstat[2][LB_N];
-  const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
+  __shared__ __attribute__((aligned(16))) __bf16 As_[GP][2][LB_M * LB_LD];     // [group slot][hi | lo]
+  __shared__ __attribute__((aligned(16))) __bf16 Bs_[GP][2][LB_N * LB_LD];
+  __shared__ float colred_[GP][4][LB_N];
+  __shared__ float colstat_[GP][3][LB_N];                                       // mean | invstd | sum of squared deviations
+  const int gsel = threadIdx.x >> 8, t = threadIdx.x & 255, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
+  auto& As = As_[gsel];
+  auto& Bs = Bs_[gsel];
+  auto& colred = colred_[gsel];
+  auto& colstat = colstat_[gsel];
   const int n0 = blockIdx.x * LB_N;
-  if (blockIdx.x == 0 && t == 0 && training && nbt) nbt[0] += (int64_t)groups * stat_repeats;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && training && nbt) nbt[0] += (int64_t)groups * stat_repeats;
   // `groups` independent batches of M rows share the weights and are normalised with their OWN batch statistics, one
   // after the other (a generator's two forwards of one training iteration, network_tests.py:294 and 312, in one launch:
   // the running statistics take the updates in that order); `stat_repeats` applies a group's running-statistics update
@@ -42,7 +50,9 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* x, cons
   const float* const x_all = x;
   float* const out_all = out;
   float* const y_all = y_out;
-  for (int grp = 0; grp < groups; ++grp) {
+  for (int grp0 = 0; grp0 < groups; grp0 += GP) {
+  const bool live = grp0 + gsel < groups;          // an odd tail: the second slot repeats the last group and stores nothing
+  const int grp = live ? grp0 + gsel : groups - 1;
   x = x_all + (int64_t)grp * M * K;
   out = out_all + (int64_t)grp * M * N;
   y_out = y_all ? y_all + (int64_t)grp * M * N : nullptr;
@@ -175,22 +185,25 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* x, cons
       const float m2 = ((colred[0][t] + colred[1][t]) + colred[2][t]) + colred[3][t];
       const float var_b = m2 / (float)M;
       colstat[1][t] = 1.0f / sqrtf(var_b + eps);
+      colstat[2][t] = m2;
       const int n = n0 + t;
-      if (n < N) {
+      if (n < N && live) {
         save_mean_g[n] = colstat[0][t];
         save_invstd_g[n] = colstat[1][t];
-        if (running_mean) {
-          float rm = running_mean[n], rv = running_var[n];
-          for (int rep = 0; rep < stat_repeats; ++rep) {
-            rm = (1.f - momentum) * rm + momentum * colstat[0][t];
-            rv = (1.f - momentum) * rv + momentum * (m2 / (float)max(M - 1, 1));
-          }
-          running_mean[n] = rm;
-          running_var[n] = rv;
-        }
       }
     }
     __syncthreads();
+    if (gsel == 0 && t < LB_N && n0 + t < N && running_mean) {
+      const int n = n0 + t;
+      float rm = running_mean[n], rv = running_var[n];
+      for (int g = 0; g < GP && grp0 + g < groups; ++g)
+        for (int rep = 0; rep < stat_repeats; ++rep) {
+          rm = (1.f - momentum) * rm + momentum * colstat_[g][0][t];
+          rv = (1.f - momentum) * rv + momentum * (colstat_[g][2][t] / (float)max(M - 1, 1));
+        }
+      running_mean[n] = rm;
+      running_var[n] = rv;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) invstd[j] = colstat[1][16 * j + lr];
   } else {
@@ -199,13 +212,13 @@ __global__ __launch_bounds__(256) void linear_bn_act_kernel(const float* x, cons
       const int n = n0 + 16 * j + lr;
       mean[j] = n < N ? running_mean[n] : 0.f;
       invstd[j] = n < N ? 1.0f / sqrtf(running_var[n] + eps) : 0.f;
-      if (n < N && lg == 0 && wv == 0) { save_mean_g[n] = mean[j]; save_invstd_g[n] = invstd[j]; }
+      if (n < N && lg == 0 && wv == 0 && live) { save_mean_g[n] = mean[j]; save_invstd_g[n] = invstd[j]; }
     }
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + 16 * j + lr;
-    if (n >= N) continue;
+    if (n >= N || !live) continue;
     const float alpha = invstd[j] * gamma[n], bt = beta[n];
     if (M == LB_M && act == GDM_ACT_SIGMOID && !y_out) {
       // the generators' case (full batch, sigmoid, forward only): no per-element branch, so the 16 stores of a column
@@ -251,14 +264,15 @@ extern "C" int gdm_linear_bn_act_fwd(const float* x, const float* w, const float
   GDM_REQUIRE(!training || M > 1, "gdm_linear_bn_act_fwd: training-mode batch norm needs more than 1 row");
   GDM_REQUIRE(training || (running_mean && running_var), "gdm_linear_bn_act_fwd: eval mode needs running statistics");
   const bool vec = (K % 4 == 0) && ((((uintptr_t)x | (uintptr_t)w) & 15) == 0);
-  if (vec)
-    hipLaunchKernelGGL(linear_bn_act_kernel<true>, dim3((N + LB_N - 1) / LB_N), dim3(256), 0, (hipStream_t)stream, x, w,
-                       bias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, act, training, M,
-                       N, K, y_out, out, save_mean, save_invstd, groups, stat_repeats);
-  else
-    hipLaunchKernelGGL(linear_bn_act_kernel<false>, dim3((N + LB_N - 1) / LB_N), dim3(256), 0, (hipStream_t)stream, x, w,
-                       bias, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, act, training,
-                       M, N, K, y_out, out, save_mean, save_invstd, groups, stat_repeats);
+  const dim3 grid((N + LB_N - 1) / LB_N);
+  hipStream_t s = (hipStream_t)stream;
+#define GDM_LB_LAUNCH(VEC_, GP_)                                                                                          \
+  hipLaunchKernelGGL((linear_bn_act_kernel<VEC_, GP_>), grid, dim3(256 * GP_), 0, s, x, w, bias, gamma, beta, running_mean, \
+                     running_var, num_batches_tracked, momentum, eps, act, training, M, N, K, y_out, out, save_mean,       \
+                     save_invstd, groups, stat_repeats)
+  if (groups >= 2) { if (vec) GDM_LB_LAUNCH(true, 2); else GDM_LB_LAUNCH(false, 2); }
+  else { if (vec) GDM_LB_LAUNCH(true, 1); else GDM_LB_LAUNCH(false, 1); }
+#undef GDM_LB_LAUNCH
   GDM_LAUNCH_OK("gdm_linear_bn_act_fwd");
   return GDM_OK;
 }

@@ -23,18 +23,18 @@ constexpr int W1K = 40, W2FK = 264, W2BK = 136;                      // padded K
 
 struct Dims {
   int T, OW1, OW2, G1, G2, XWP, W1P, W2P, KFC;
-  __host__ __device__ explicit Dims(int t) {
-    T = t; OW1 = t / 2; OW2 = (OW1 - 2) / 2 + 1; G1 = (OW1 + 3) / 4; G2 = OW2 / 4;
-    XWP = t + 2; W1P = 4 * G1 + 1; W2P = OW2 + 2; KFC = 32 * OH2 * OW2;
-  }
+  __host__ __device__ constexpr explicit Dims(int t)
+      : T(t), OW1(t / 2), OW2((t / 2 - 2) / 2 + 1), G1((t / 2 + 3) / 4), G2(((t / 2 - 2) / 2 + 1) / 4), XWP(t + 2),
+        W1P(4 * ((t / 2 + 3) / 4) + 1), W2P((t / 2 - 2) / 2 + 3), KFC(32 * OH2 * ((t / 2 - 2) / 2 + 1)) {}
   // image sizes in bf16 elements, rounded to 16 bytes so that every image starts 16-byte aligned
-  __host__ __device__ int xs_elems() const { return ((H + 3) * XWP * 2 + 7) & ~7; }
-  __host__ __device__ int h1_elems() const { return ((OH1 + 2) * W1P * 16 + 7) & ~7; }
-  __host__ __device__ int d2_elems() const { return ((OH2 + 2) * W2P * 32 + 7) & ~7; }
+  __host__ __device__ constexpr int xs_elems() const { return ((H + 3) * XWP * 2 + 7) & ~7; }
+  __host__ __device__ constexpr int h1_elems() const { return ((OH1 + 2) * W1P * 16 + 7) & ~7; }
+  __host__ __device__ constexpr int d2_elems() const { return ((OH2 + 2) * W2P * 32 + 7) & ~7; }
 };
 constexpr int W_ELEMS = 16 * W1K + 32 * W2FK + 4 * 16 * W2BK;        // weight images kept in LDS
-// slab layout (floats): [0] loss, [1] dbfc, [2..18) db1, [18..50) db2, [50..562) dW1, [562..8754) dW2, then dWfc (KFC)
-constexpr int S_LOSS = 0, S_DBFC = 1, S_DB1 = 2, S_DB2 = 18, S_DW1 = 50, S_DW2 = 562, S_DWFC = 8754;
+// slab layout (floats): [0] loss, [1] dbfc, [2..18) db1, [18..50) db2, [50..52) unused, [52..564) dW1, [564..8756) dW2,
+// then dWfc (KFC): the three matrices start on 16-byte boundaries (vector stores)
+constexpr int S_LOSS = 0, S_DBFC = 1, S_DB1 = 2, S_DB2 = 18, S_PAD = 50, S_DW1 = 52, S_DW2 = 564, S_DWFC = 8756;
 
 __device__ __forceinline__ bf16x4 tr16(const __bf16* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)p);
@@ -44,6 +44,19 @@ __device__ __forceinline__ bf16x8 ld8_b64x2(const __bf16* p) {       // 8 bf16 f
   return cat8(*(const bf16x4*)p, *(const bf16x4*)(p + 4));
 }
 __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : 0.2f * v; }
+
+// -DGDM_DCNN_STAMPS: thread 0 of workgroup 0 sums the shader-clock span of every phase over its samples and prints them
+// (measuring builds only; tools/calls)
+#ifdef GDM_DCNN_STAMPS
+#define DSTAMP_DECL uint64_t st_last = __builtin_amdgcn_s_memtime(), st_ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int st_n = 0
+#define DSTAMP(k) do { if (threadIdx.x == 0) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); st_ph[k] += now_ - st_last; st_last = now_; } } while (0)
+#define DSTAMP_FLUSH do { if (threadIdx.x == 0 && blockIdx.x == 0) { printf("dcnn stamps (cycles per sample, %d samples):", st_n); \
+  for (int k_ = 0; k_ < 10; ++k_) printf(" P%d=%llu", k_, (unsigned long long)(st_ph[k_] / (st_n > 0 ? st_n : 1))); printf("\n"); } } while (0)
+#else
+#define DSTAMP_DECL
+#define DSTAMP(k)
+#define DSTAMP_FLUSH
+#endif
 
 // ---- weight pack: bf16 images + permuted fc weight + fp32 biases ---------------------------------------------------
 // pack (bytes): [W1img 16xW1K | W2f 32xW2FK | W2b 4x16xW2BK | wfp KFC] bf16, then [b1 16 | b2 32 | bfc 1] fp32
@@ -83,13 +96,17 @@ __global__ __launch_bounds__(256) void dcnn_pack_kernel(const float* __restrict_
 }
 
 // ---- the fused per-sample kernel ---------------------------------------------------------------------------------------
+// The roll length T is a template parameter (six values pass supported()): every LDS offset is then lane term +
+// immediate, and the divisions by row lengths are multiplications.  With T as a run-time value the phases spent more
+// issue cycles on index arithmetic than on their MFMAs and LDS reads.
+template <int T>
 __global__ __launch_bounds__(NTHREADS) void dcnn_fused_kernel(const float* __restrict__ xa, int bsplit,
                                                               const float* __restrict__ p0,
-                                                              const float* __restrict__ p1, int B, int T, float ya,
+                                                              const float* __restrict__ p1, int B, float ya,
                                                               float yb, const __bf16* __restrict__ pk,
                                                               float* __restrict__ logits, float* __restrict__ slabs,
                                                               int slab_width, int want_grad) {
-  const Dims d(T);
+  constexpr Dims d(T);
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   __bf16* xs = (__bf16*)dyn_smem;                 // [(H+3)][XWP][2]   index ((r+1)*XWP + (c+1))*2 + ch
   __bf16* h1s = xs + d.xs_elems();                // [(OH1+2)][W1P][16]
@@ -98,27 +115,21 @@ __global__ __launch_bounds__(NTHREADS) void dcnn_fused_kernel(const float* __res
   __bf16* w2fs = w1s + 16 * W1K;                  // 32 x W2FK
   __bf16* w2bs = w2fs + 32 * W2FK;                // 4 x 16 x W2BK
   float* red = (float*)(w2bs + 4 * 16 * W2BK);    // 64 floats of block-reduction scratch
+  float* bias_s = red + 64;                       // b1 16 | b2 32 | bfc 1 (read at the phase that needs them: a register
+                                                  // each for the whole kernel pushed the T = 50 instance into scratch)
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4, q4 = lr >> 2, p4 = lr & 3;
   const __bf16* wfp = pk + W_ELEMS;
   const float* biases = (const float*)(pk + W_ELEMS + d.KFC);
-  const int XWP = d.XWP, W1P = d.W1P, W2P = d.W2P, OW1 = d.OW1, OW2 = d.OW2;
+  constexpr int XWP = d.XWP, W1P = d.W1P, W2P = d.W2P, OW1 = d.OW1, OW2 = d.OW2;
 
   // zero every LDS image once (halos stay zero for the whole kernel), then bring the weight images in
   {
     const int nz = (d.xs_elems() + d.h1_elems() + d.d2_elems()) / 8;
     for (int i = t; i < nz; i += NTHREADS) ((f32x4*)xs)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int i = t; i < W_ELEMS / 8; i += NTHREADS) ((f32x4*)w1s)[i] = ((const f32x4*)pk)[i];
+    if (t < 49) bias_s[t] = biases[t];
   }
   __syncthreads();
-  const bf16x8 a_w1 = *(const bf16x8*)&w1s[lr * W1K + 8 * lg];     // conv1's weight fragment lives in registers
-  float b1v[4], b2v[2][4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    b1v[r] = biases[4 * lg + r];
-    b2v[0][r] = biases[16 + 4 * lg + r];
-    b2v[1][r] = biases[32 + 4 * lg + r];
-  }
-  const float bfc = biases[48];
 
   // gradient accumulators that live across all samples of this workgroup
   f32x4 acc_w2[2][2], acc_w1[2];
@@ -138,79 +149,167 @@ __global__ __launch_bounds__(NTHREADS) void dcnn_fused_kernel(const float* __res
   for (int e = 0; e < 8; ++e) db2p[e] = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) db1p[r] = 0.f;
-  const int n_chunks = d.KFC / 8;
+  constexpr int n_chunks = d.KFC / 8;
 
+  // input staging: thread t owns float4 chunks t, t + 512, ... of BOTH planes (H*T/4 <= 512 * XCH chunks per plane)
+  constexpr int XCH = 4;
+  constexpr int per_plane = H * T / 4;
+  static_assert(per_plane <= NTHREADS * XCH && OW1 <= 32, "input staging registers / conv1 column tiles");
+  f32x4 xr[XCH][2];
+  int x_lds[XCH], x_wrap = 0;                      // LDS element index of the chunk's first pixel; bit 4k+e: pixel e is in the next row
+#pragma unroll
+  for (int k = 0; k < XCH; ++k) {
+    const int j = min(t + NTHREADS * k, per_plane - 1), r0 = (4 * j) / T, c0 = (4 * j) % T;
+#pragma unroll
+    for (int e = 1; e < 4; ++e) x_wrap |= (c0 + e >= T ? 1 : 0) << (4 * k + e);
+    x_lds[k] = ((r0 + 1) * XWP + (c0 + 1)) * 2;
+  }
+  auto x_issue = [&](int b) {
+    const float* pl0 = b < bsplit ? xa + (int64_t)b * 2 * H * T : p0 + (int64_t)(b - bsplit) * H * T;
+    const float* pl1 = b < bsplit ? pl0 + H * T : p1 + (int64_t)(b - bsplit) * H * T;
+#pragma unroll
+    for (int k = 0; k < XCH; ++k) {
+      const int j = min(t + NTHREADS * k, per_plane - 1);
+      xr[k][0] = *(const f32x4*)(pl0 + 4 * j);
+      xr[k][1] = *(const f32x4*)(pl1 + 4 * j);
+    }
+  };
+  auto x_store = [&]() {
+#pragma unroll
+    for (int k = 0; k < XCH; ++k) {
+      if (t + NTHREADS * k >= per_plane) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // a chunk may run over the end of its image row (T % 4 != 0): the next row starts 2 halo pixels further on
+        const int idx = x_lds[k] + 2 * e + ((x_wrap >> (4 * k + e)) & 1) * 4;
+        bf16x2 v;
+        v[0] = (__bf16)xr[k][0][e];
+        v[1] = (__bf16)xr[k][1][e];
+        *(bf16x2*)&xs[idx] = v;
+      }
+    }
+  };
+  // the fc weight chunks of this thread never change: registers for the whole kernel
+  bf16x8 wfc_c[FC_CH];
+#pragma unroll
+  for (int i = 0; i < FC_CH; ++i) {
+    const int qd = t + NTHREADS * i;
+    wfc_c[i] = __builtin_bit_cast(bf16x8, (f32x4){0.f, 0.f, 0.f, 0.f});
+    if (qd < n_chunks) wfc_c[i] = *(const bf16x8*)&wfp[(int64_t)qd * 8];
+  }
+  if ((int)blockIdx.x < B) x_issue(blockIdx.x);
+  DSTAMP_DECL;
+  const int lr0 = lr, lg0 = lg, q40 = q4, p40 = p4, wv0 = wv;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    // ---- P0: input planes -> xs (bf16, channel-interleaved)
-    {
-      const float* pl0 = b < bsplit ? xa + (int64_t)b * 2 * H * T : p0 + (int64_t)(b - bsplit) * H * T;
-      const float* pl1 = b < bsplit ? pl0 + H * T : p1 + (int64_t)(b - bsplit) * H * T;
-      const int per_plane = H * T / 4;             // float4 chunks (H*T is a multiple of 4)
-      for (int i = t; i < 2 * per_plane; i += NTHREADS) {
-        const int ch = i >= per_plane, j = ch ? i - per_plane : i;
-        const f32x4 v = *(const f32x4*)((ch ? pl1 : pl0) + 4 * j);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int idx = 4 * j + e, r = idx / T, c = idx % T;
-          xs[((r + 1) * XWP + (c + 1)) * 2 + ch] = (__bf16)v[e];
-        }
-      }
-    }
+    // An opaque zero added to the lane coordinates: the phases' (loop-invariant) LDS offsets are then recomputed per
+    // sample with a few VALU each instead of being hoisted out of this loop, where ~70 of them lived in scratch memory
+    int opq = 0;
+    asm volatile("" : "+s"(opq));
+    const int lr = lr0 + opq, lg = lg0 + opq, q4 = q40 + opq, p4 = p40 + opq, wv = wv0 + opq;
+    DSTAMP(9);
+#ifdef GDM_DCNN_STAMPS
+    ++st_n;
+#endif
+    // ---- P0: input planes (already in registers) -> xs (bf16, channel-interleaved: one 4-byte store per pixel).  The
+    //          NEXT sample's planes are requested at the end of P6 (or after P3 without gradients): late enough that
+    //          the 32 staging registers are free during the register-hungry phases, ~3 us before they are needed
+    x_store();
     __syncthreads();
-    // ---- P1: conv1 + LeakyReLU -> h1s.  unit = (output row, 16-column tile)
+    DSTAMP(0);
+    // Index arithmetic of all phases below: every LDS address is written as (lane term, a few VALU per sample) + (a
+    // compile-time offset that lands in the instruction's offset field).  Left to "row = unit / tiles" style indexing
+    // the phases issued 3-4x more address VALU than MFMA + LDS instructions and were bound by exactly that.
+    //
+    // ---- P1: conv1 + LeakyReLU -> h1s.  unit = (output row, 16-column tile); wave wv owns units wv + 8j: with two
+    //          column tiles that is tile wv & 1 of rows (wv >> 1) + 4j, with one tile rows wv + 8j.  EIGHT units are in
+    //          flight per wave (reads, MFMAs, stores of the eight are independent chains: one unit at a time is a
+    //          ~500-cycle latency chain)
     {
-      const int ntile = (OW1 + 15) / 16;
-      for (int u = wv; u < OH1 * ntile; u += NWAVES) {
-        const int oh = u / ntile, ow = 16 * (u % ntile) + lr, owc = min(ow, OW1 - 1);
-        // k = 8*lg + j: kh = lg, (kw, ci) = j  -> 8 contiguous bf16 starting at input (2oh-1+lg, 2ow-1, 0)
-        const bf16x8 bb = ld8_b64x2(&xs[((2 * oh + lg) * XWP + 2 * owc) * 2]);
-        const f32x4 c = mfma16(a_w1, bb, (f32x4){0.f, 0.f, 0.f, 0.f});
+      constexpr int tsh = OW1 > 16 ? 1 : 0, NJ = (OH1 << tsh) / NWAVES, RSTEP = NWAVES >> tsh;   // units per wave, row step
+      constexpr int UB = 8;
+      static_assert(NJ % UB == 0, "conv1 units are dealt in whole batches");
+      const int ow = 16 * (wv & tsh) + lr, owc = min(ow, OW1 - 1), oh0 = wv >> tsh;
+      const bf16x8 a_w1 = *(const bf16x8*)&w1s[lr * W1K + 8 * lg];
+      const f32x4 b1v = *(const f32x4*)&bias_s[4 * lg];
+      // k = 8*lg + j: kh = lg, (kw, ci) = j  -> 8 contiguous bf16 starting at input (2oh-1+lg, 2ow-1, 0)
+      const __bf16* xb = &xs[((2 * oh0 + lg) * XWP + 2 * owc) * 2];
+      __bf16* hb = &h1s[((oh0 + 1) * W1P + (ow + 1)) * 16 + 4 * lg];
+#pragma unroll
+      for (int j0 = 0; j0 < NJ; j0 += UB) {
+        bf16x8 bb[UB];
+#pragma unroll
+        for (int q = 0; q < UB; ++q) bb[q] = ld8_b64x2(xb + (j0 + q) * (2 * RSTEP * XWP * 2));
+        f32x4 c[UB];
+#pragma unroll
+        for (int q = 0; q < UB; ++q) c[q] = mfma16(a_w1, bb[q], (f32x4){0.f, 0.f, 0.f, 0.f});
         if (ow < OW1) {
-          bf16x4 hv;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hv[r] = (__bf16)leaky(c[r] + b1v[r]);
-          *(bf16x4*)&h1s[((oh + 1) * W1P + (ow + 1)) * 16 + 4 * lg] = hv;
+          for (int q = 0; q < UB; ++q) {
+            bf16x4 hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = (__bf16)leaky(c[q][r] + b1v[r]);
+            *(bf16x4*)(hb + (j0 + q) * (RSTEP * W1P * 16)) = hv;
+          }
         }
       }
     }
     __syncthreads();
-    // ---- P2: conv2 + LeakyReLU -> d2s (holds h2 until the gradient overwrites it).  unit = output row (OW2 <= 16)
-    for (int oh = wv; oh < OH2; oh += NWAVES) {
+    DSTAMP(1);
+    // ---- P2: conv2 + LeakyReLU -> d2s (holds h2 until the gradient overwrites it).  unit = output row (OW2 <= 16);
+    //          the wave's four rows (wv, wv+8, ...) advance together: eight independent accumulation chains, a
+    //          weight fragment is read once for the four rows, the fragments of k-step s+1 are read before the MFMAs of s.
+    //          k-step ks holds taps 2ks + h (h = lg >> 1): kh = ks >> 1, kw = 2 (ks & 1) + h
+    {
+      static_assert(OH2 == 4 * NWAVES, "a wave owns four conv2 output rows");
       const int owc = min(lr, OW2 - 1);
-      f32x4 c[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+      const __bf16* hb = &h1s[((2 * wv) * W1P + 2 * owc + (lg >> 1)) * 16 + 8 * (lg & 1)];
+      const __bf16* wb = &w2fs[lr * W2FK + 8 * lg];
+      f32x4 c[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) c[q][0] = c[q][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      auto frags = [&](int ks, bf16x8 (&a)[2], bf16x8 (&bb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8*)(wb + i * 16 * W2FK + 32 * ks);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          bb[q] = *(const bf16x8*)(hb + ((2 * NWAVES * q + (ks >> 1)) * W1P + 2 * (ks & 1)) * 16);
+      };
+      bf16x8 a[2][2], bb[2][4];
+      frags(0, a[0], bb[0]);
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const int tap = 2 * ks + (lg >> 1), kh = tap >> 2, kw = tap & 3;
-        const bf16x8 bb = *(const bf16x8*)&h1s[((2 * oh + kh) * W1P + 2 * owc + kw) * 16 + 8 * (lg & 1)];
+        if (ks + 1 < 8) frags(ks + 1, a[(ks + 1) & 1], bb[(ks + 1) & 1]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const bf16x8 a = *(const bf16x8*)&w2fs[(16 * i + lr) * W2FK + 32 * ks + 8 * lg];
-          c[i] = mfma16(a, bb, c[i]);
-        }
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) c[q][i] = mfma16(a[ks & 1][i], bb[ks & 1][q], c[q][i]);
       }
       if (lr < OW2) {
+        const f32x4 b2v[2] = {*(const f32x4*)&bias_s[16 + 4 * lg], *(const f32x4*)&bias_s[32 + 4 * lg]};
+        __bf16* sb = &d2s[((wv + 1) * W2P + (lr + 1)) * 32 + 4 * lg];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          bf16x4 hv;
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hv[r] = (__bf16)leaky(c[i][r] + b2v[i][r]);
-          *(bf16x4*)&d2s[((oh + 1) * W2P + (lr + 1)) * 32 + 16 * i + 4 * lg] = hv;
-        }
+          for (int i = 0; i < 2; ++i) {
+            bf16x4 hv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = (__bf16)leaky(c[q][i][r] + b2v[i][r]);
+            *(bf16x4*)(sb + NWAVES * q * W2P * 32 + 16 * i) = hv;
+          }
       }
     }
     __syncthreads();
+    DSTAMP(2);
     // ---- P3: fc dot product (channels-last flatten order, permuted weight) -> logit, loss, dl
-    bf16x8 h2c[FC_CH], wfc_c[FC_CH];
+    bf16x8 h2c[FC_CH];
     float part = 0.f;
 #pragma unroll
     for (int i = 0; i < FC_CH; ++i) {
       const int qd = t + NTHREADS * i;
       h2c[i] = __builtin_bit_cast(bf16x8, (f32x4){0.f, 0.f, 0.f, 0.f});
-      wfc_c[i] = h2c[i];
       if (qd < n_chunks) {
         const int pix = qd >> 2, c8 = (qd & 3) * 8, oh = pix / OW2, ow = pix % OW2;
         h2c[i] = *(const bf16x8*)&d2s[((oh + 1) * W2P + (ow + 1)) * 32 + c8];
-        wfc_c[i] = *(const bf16x8*)&wfp[(int64_t)qd * 8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) part = fmaf((float)h2c[i][e], (float)wfc_c[i][e], part);
       }
@@ -218,7 +317,7 @@ __global__ __launch_bounds__(NTHREADS) void dcnn_fused_kernel(const float* __res
     part = wave_sum(part);
     if (l == 0) red[wv] = part;
     __syncthreads();
-    float z = bfc;
+    float z = bias_s[48];
 #pragma unroll
     for (int w = 0; w < NWAVES; ++w) z += red[w];
     const bool first = b < bsplit;
@@ -229,6 +328,8 @@ __global__ __launch_bounds__(NTHREADS) void dcnn_fused_kernel(const float* __res
       loss_acc += (fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z)))) / cnt;
       dbfc_acc += dl;
     }
+    DSTAMP(3);
+    if (!want_grad) x_issue(min(b + (int)gridDim.x, B - 1));       // past the end: re-reads the last sample (never stored)
     if (want_grad) {
       // ---- P4: dW_fc accumulation and the gradient of conv2's output (through its LeakyReLU), in place in d2s
 #pragma unroll
@@ -249,80 +350,142 @@ __global__ __launch_bounds__(NTHREADS) void dcnn_fused_kernel(const float* __res
         }
       }
       __syncthreads();
-      // ---- P5: conv2 weight gradient: contraction over pixels, 8 groups of 4 row-adjacent pixels per k-step;
-      //          wave wv owns taps 2wv, 2wv+1 (both 16-channel m-tiles)
-      const int G2 = d.G2, ngroups2 = OH2 * G2;
-      for (int g0 = 0; g0 < ngroups2; g0 += 8) {
-        const int ga = g0 + 2 * lg, gb = ga + 1;
-        const int ra = ga / G2, ca = (ga % G2) * 4 + q4, rb = gb / G2, cb = (gb % G2) * 4 + q4;
-        bf16x8 a[2];
+      DSTAMP(4);
+      // ---- P5: conv2 weight gradient: contraction over pixels, 8 groups of 4 row-adjacent pixels per k-step; wave wv
+      //          owns taps 2wv, 2wv+1 (both 16-channel m-tiles): kh = wv >> 1, kw = 2 (wv & 1) + tt.  k-step s covers
+      //          the 8 rows 8 (s / G2) .. +7 of column group s % G2; lane group lg takes rows +2lg and +2lg+1.  The
+      //          fragments of k-step s+1 are read before the MFMAs of k-step s (two register sets)
+      {
+        constexpr int G2 = d.G2, NS = (OH2 / 8) * G2;
+        const __bf16* ab = &d2s[((2 * lg + 1) * W2P + q4 + 1) * 32 + 4 * p4];
+        const __bf16* bb_ = &h1s[((4 * lg + (wv >> 1)) * W1P + 2 * q4 + 2 * (wv & 1)) * 16 + 4 * p4];
+        auto frags = [&](int st, bf16x8 (&a)[2], bf16x8 (&bb)[2]) {
+          const int rblk = st / G2, cg = st % G2;                         // compile-time after unrolling
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-          a[i] = cat8(tr16(&d2s[((ra + 1) * W2P + ca + 1) * 32 + 16 * i + 4 * p4]),
-                      tr16(&d2s[((rb + 1) * W2P + cb + 1) * 32 + 16 * i + 4 * p4]));
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const int tap = 2 * wv + tt, kh = tap >> 2, kw = tap & 3;
-          const bf16x8 bb = cat8(tr16(&h1s[((2 * ra + kh) * W1P + 2 * ca + kw) * 16 + 4 * p4]),
-                                 tr16(&h1s[((2 * rb + kh) * W1P + 2 * cb + kw) * 16 + 4 * p4]));
-#pragma unroll
-          for (int i = 0; i < 2; ++i) acc_w2[i][tt] = mfma16(a[i], bb, acc_w2[i][tt]);
-        }
-      }
-      __syncthreads();
-      // ---- P6: conv2 data gradient (stride-2 transposed conv by parity class) + LeakyReLU' of conv1, in place in h1s
-      for (int u = wv; u < OH1 * 2; u += NWAVES) {
-        const int ih = u >> 1, pc = u & 1, iw = pc + 2 * lr, iwc = min(iw, OW1 - 1 - ((OW1 - 1 - pc) & 1));
-        const int ph = (ih + 1) & 1, pw = (pc + 1) & 1, cl = ph * 2 + pw;
-        f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t2 = 0; t2 < 4; ++t2) {
-          const int kh = ph + 2 * (t2 >> 1), kw = pw + 2 * (t2 & 1);
-          const int oh = (ih + 1 - kh) / 2, ow = (iwc + 1 - kw) / 2;     // exact: parities match by construction
-          const bf16x8 bb = *(const bf16x8*)&d2s[((oh + 1) * W2P + (ow + 1)) * 32 + 8 * lg];
-          const bf16x8 a = *(const bf16x8*)&w2bs[(cl * 16 + lr) * W2BK + 32 * t2 + 8 * lg];
-          c = mfma16(a, bb, c);
-        }
-        if (iw < OW1) {
-          __bf16* hp = &h1s[((ih + 1) * W1P + (iw + 1)) * 16 + 4 * lg];
-          const bf16x4 hv = *(const bf16x4*)hp;
-          bf16x4 gv;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float gy = c[r] * ((float)hv[r] > 0.f ? 1.f : 0.2f);
-            db1p[r] += gy;
-            gv[r] = (__bf16)gy;
+          for (int i = 0; i < 2; ++i) {
+            const __bf16* pa = ab + (8 * rblk * W2P + 4 * cg) * 32 + 16 * i;
+            a[i] = cat8(tr16(pa), tr16(pa + W2P * 32));
           }
-          *(bf16x4*)hp = gv;
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const __bf16* pb = bb_ + (16 * rblk * W1P + 8 * cg + tt) * 16;
+            bb[tt] = cat8(tr16(pb), tr16(pb + 2 * W1P * 16));
+          }
+        };
+        bf16x8 a[2][2], bb[2][2];
+        frags(0, a[0], bb[0]);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          if (st + 1 < NS) frags(st + 1, a[(st + 1) & 1], bb[(st + 1) & 1]);
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc_w2[i][tt] = mfma16(a[st & 1][i], bb[st & 1][tt], acc_w2[i][tt]);
         }
       }
       __syncthreads();
-      // ---- P7: conv1 weight gradient: contraction over pixels (groups of 4 row-adjacent pixels, 8 per k-step);
-      //          the k-steps are dealt over the waves, every wave accumulates both 16-column halves of (kh,kw,ci)
-      const int G1 = d.G1, ngroups1 = OH1 * G1;
-      for (int g0 = 8 * wv; g0 < ngroups1; g0 += 8 * NWAVES) {
-        const int ga = g0 + 2 * lg, gb = ga + 1;
-        const int ra = ga / G1, ca = (ga % G1) * 4 + q4, rb = gb / G1, cb = (gb % G1) * 4 + q4;
-        const bf16x8 a = cat8(tr16(&h1s[((ra + 1) * W1P + ca + 1) * 16 + 4 * p4]),
-                              tr16(&h1s[((rb + 1) * W1P + cb + 1) * 16 + 4 * p4]));
+      DSTAMP(5);
+      // ---- P6: conv2 data gradient (stride-2 transposed conv by parity class) + LeakyReLU' of conv1, in place in h1s.
+      //          unit = (input row ih, column parity pc) = 16 same-parity pixels.  Wave wv owns ONE parity class (its
+      //          four weight fragments are read once per sample): column parity pc = wv & 1, row parity rp = (wv >> 1) & 1,
+      //          and the 16 rows ih = rp + 2j + 32 (wv >> 2).  kh = ph + 2a, kw = pw + 2b for tap t2 = 2a + b:
+      //              oh = (ih + 1 - ph) / 2 - a = c + j - a,      ow = (iw + 1 - pw) / 2 - b
+      //          so unit j's a = 1 fragments are unit j-1's a = 0 fragments: a batch of four units reads 8 new d2s
+      //          fragments (+2 carried over) instead of 16, and its four MFMA chains are independent
+      {
+        const int pc = wv & 1, rp = (wv >> 1) & 1, half = wv >> 2, ph = (rp + 1) & 1, pw = (pc + 1) & 1, cl = ph * 2 + pw;
+        const int iw = pc + 2 * lr, iwc = min(iw, OW1 - 1 - ((OW1 - 1 - pc) & 1));
+        bf16x8 a[4];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          // column block 4p..4p+3 of n = (kh_local = p>>1, kw = 2(p&1)+{0,1}, ci): 4 contiguous bf16 of the input row
-          const int kh = 2 * nt + (p4 >> 1), kwo = 2 * (p4 & 1);
-          const bf16x8 bb = cat8(tr16(&xs[((2 * ra + kh) * XWP + 2 * ca + kwo) * 2]),
-                                 tr16(&xs[((2 * rb + kh) * XWP + 2 * cb + kwo) * 2]));
-          acc_w1[nt] = mfma16(a, bb, acc_w1[nt]);
+        for (int t2 = 0; t2 < 4; ++t2) a[t2] = *(const bf16x8*)&w2bs[(cl * 16 + lr) * W2BK + 32 * t2 + 8 * lg];
+        // d2s record of row c - 1 (= unit 0's a = 1 row), column ow(b = 1): every fragment is a non-negative offset away
+        const int crow = ((rp + 1 - ph) >> 1) + 16 * half;                 // c: dy2 row of unit 0, a = 0
+        const __bf16* db = &d2s[((crow - 1 + 1) * W2P + (((iwc + 1 - pw) >> 1) - 1 + 1)) * 32 + 8 * lg];
+        __bf16* hb = &h1s[((rp + 32 * half + 1) * W1P + (min(iw, OW1 - 1) + 1)) * 16 + 4 * lg];
+        bf16x8 rowf[5][2];                                                 // [dy2 row c+4m-1 .. c+4m+3][b]
+#pragma unroll
+        for (int bq = 0; bq < 2; ++bq) rowf[0][bq] = *(const bf16x8*)(db + (1 - bq) * 32);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          f32x4 c[4];
+          bf16x4 hv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            c[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            hv[q] = *(const bf16x4*)(hb + 2 * (q + 4 * m) * W1P * 16);
+#pragma unroll
+            for (int bq = 0; bq < 2; ++bq) rowf[q + 1][bq] = *(const bf16x8*)(db + ((4 * m + q + 1) * W2P + 1 - bq) * 32);
+          }
+#pragma unroll
+          for (int t2 = 0; t2 < 4; ++t2)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[q] = mfma16(a[t2], rowf[q + 1 - (t2 >> 1)][t2 & 1], c[q]);
+          if (iw < OW1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              bf16x4 gv;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float gy = c[q][r] * ((float)hv[q][r] > 0.f ? 1.f : 0.2f);
+                db1p[r] += gy;
+                gv[r] = (__bf16)gy;
+              }
+              *(bf16x4*)(hb + 2 * (q + 4 * m) * W1P * 16) = gv;
+            }
+          }
+#pragma unroll
+          for (int bq = 0; bq < 2; ++bq) rowf[0][bq] = rowf[4][bq];
+        }
+        x_issue(min(b + (int)gridDim.x, B - 1));                          // next sample's planes (see P0)
+      }
+      __syncthreads();
+      DSTAMP(6);
+      // ---- P7: conv1 weight gradient: contraction over pixels (groups of 4 row-adjacent pixels, 8 per k-step): wave wv
+      //          owns the rows 8wv .. 8wv+7 (lane group lg: rows +2lg, +2lg+1), k-step m is column group m; every wave
+      //          accumulates both 16-column halves of (kh,kw,ci); fragments of k-step m+1 are read before the MFMAs of m.
+      //          (Column groups past OW1 hold zeros in h1s, so what the x fragments read there does not matter.)
+      {
+        constexpr int G1 = d.G1;
+        static_assert(OH1 == 8 * NWAVES, "a wave owns eight conv1 output rows");
+        const __bf16* ab = &h1s[((8 * wv + 2 * lg + 1) * W1P + q4 + 1) * 16 + 4 * p4];
+        // column block 4p..4p+3 of n = (kh_local = p>>1, kw = 2(p&1)+{0,1}, ci): 4 contiguous bf16 of the input row
+        const __bf16* xb = &xs[((2 * (8 * wv + 2 * lg) + (p4 >> 1)) * XWP + 2 * q4 + 2 * (p4 & 1)) * 2];
+        auto frags = [&](int m, bf16x8& a, bf16x8 (&bb)[2]) {
+          a = cat8(tr16(ab + 4 * m * 16), tr16(ab + 4 * m * 16 + W1P * 16));
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const __bf16* px = xb + (2 * nt * XWP + 8 * m) * 2;
+            bb[nt] = cat8(tr16(px), tr16(px + 2 * XWP * 2));
+          }
+        };
+        bf16x8 a[2], bb[2][2];
+        frags(0, a[0], bb[0]);
+#pragma unroll
+        for (int m = 0; m < G1; ++m) {
+          if (m + 1 < G1) frags(m + 1, a[(m + 1) & 1], bb[(m + 1) & 1]);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc_w1[nt] = mfma16(a[m & 1], bb[m & 1][nt], acc_w1[nt]);
         }
       }
     }
     __syncthreads();     // all LDS images are free for the next sample
+    DSTAMP(7);
   }
+  DSTAMP_FLUSH;
 
   // ---- epilogue: one slab per workgroup -------------------------------------------------------------------------------
   float* slab = slabs + (int64_t)blockIdx.x * slab_width;
   if (t == 0) slab[S_LOSS] = loss_acc;
   if (!want_grad) return;
   if (t == 0) slab[S_DBFC] = dbfc_acc;
+  // Everything leaves through LDS (the activation images are dead) so that the slab is written with 16-byte, lane-
+  // contiguous stores and the per-channel bias sums are shuffles + an 8-wave sum instead of a 512-step serial loop
+  // (that loop alone was ~6 us of every launch).  All sums in fixed order.
+  float* scr = (float*)dyn_smem;
+  float* scr_w2 = scr;                              // 8192: dW2 in torch layout (o, ci, kh, kw)
+  float* scr_w1 = scr + 8192;                       // 8 x 512: per-wave dW1 partials [o][n = (kh, kw, ci)]
+  float* scr_b1 = scr + 8192 + 4096;                // 8 x 16
+  float* scr_b2 = scr_b1 + 128;                     // 8 x 32
   // dW2: wave wv holds taps 2wv, 2wv+1: C row = o (4*lg + r within m-tile i), C col = ci (lr)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -331,47 +494,57 @@ __global__ __launch_bounds__(NTHREADS) void dcnn_fused_kernel(const float* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int o = 16 * i + 4 * lg + r, tap = 2 * wv + tt;
-        slab[S_DW2 + (o * 16 + lr) * 16 + tap] = acc_w2[i][tt][r];          // torch layout (o, ci, kh, kw)
+        scr_w2[(o * 16 + lr) * 16 + tap] = acc_w2[i][tt][r];
       }
-  // dWfc (channels-last order; un-permuted by the finish kernel)
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) scr_w1[wv * 512 + (4 * lg + r) * 32 + 16 * nt + lr] = acc_w1[nt][r];
+  // db1[4*lg + r]: lanes of one lg group (16 values of lr); db2[8*(l & 3) + e]: lanes with equal l & 3
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float v = db1p[r];
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    if (lr == 0) scr_b1[wv * 16 + 4 * lg + r] = v;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float v = db2p[e];
+    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    if (l < 4) scr_b2[wv * 32 + 8 * l + e] = v;
+  }
+  // dWfc (channels-last order; un-permuted by the finish kernel): 32 contiguous bytes per lane and chunk
 #pragma unroll
   for (int i = 0; i < FC_CH; ++i) {
     const int qd = t + NTHREADS * i;
     if (qd < n_chunks) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) slab[S_DWFC + qd * 8 + e] = acc_fc[i][e];
+      f32x4* dst = (f32x4*)(slab + S_DWFC + qd * 8);
+      dst[0] = (f32x4){acc_fc[i][0], acc_fc[i][1], acc_fc[i][2], acc_fc[i][3]};
+      dst[1] = (f32x4){acc_fc[i][4], acc_fc[i][5], acc_fc[i][6], acc_fc[i][7]};
     }
   }
-  // dW1 (8 waves x 2 tiles), db1, db2: cross-wave / cross-lane sums through LDS in fixed order
-  float* scr = (float*)dyn_smem;                   // the activation images are dead now
   __syncthreads();
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) scr[wv * 512 + (4 * lg + r) * 32 + 16 * nt + lr] = acc_w1[nt][r];   // [o][n=(kh,kw,ci)]
-#pragma unroll
-  for (int r = 0; r < 4; ++r) scr[4096 + t * 4 + r] = db1p[r];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) scr[4096 + 2048 + t * 8 + e] = db2p[e];
-  __syncthreads();
+  for (int k = 0; k < 8192 / 4 / NTHREADS; ++k) ((f32x4*)(slab + S_DW2))[t + NTHREADS * k] = ((const f32x4*)scr_w2)[t + NTHREADS * k];
   {
-    float s = 0.f;                                  // dW1: 512 outputs, one per thread
+    float s_ = 0.f;                                 // dW1: 512 outputs, one per thread
 #pragma unroll
-    for (int w = 0; w < NWAVES; ++w) s += scr[w * 512 + t];
+    for (int w = 0; w < NWAVES; ++w) s_ += scr_w1[w * 512 + t];
     const int o = t >> 5, n = t & 31, kh = n >> 3, kw = (n >> 1) & 3, ci = n & 1;
-    slab[S_DW1 + ((o * 2 + ci) * 4 + kh) * 4 + kw] = s;                      // torch layout (o, ci, kh, kw)
+    slab[S_DW1 + ((o * 2 + ci) * 4 + kh) * 4 + kw] = s_;                     // torch layout (o, ci, kh, kw)
   }
-  if (t < 16) {                                     // db1[c]: lanes with lg = c/4 of every wave hold register c%4
-    const int c = t, g = c >> 2, r = c & 3;
-    float s = 0.f;
-    for (int th = 0; th < NTHREADS; ++th)
-      if (((th & 63) >> 4) == g) s += scr[4096 + th * 4 + r];
-    slab[S_DB1 + c] = s;
-  } else if (t >= 64 && t < 96) {                   // db2[c]: threads with (t & 3) == c/8 hold element c%8
-    const int c = t - 64, g = c >> 3, e = c & 7;
-    float s = 0.f;
-    for (int th = g; th < NTHREADS; th += 4) s += scr[4096 + 2048 + th * 8 + e];
-    slab[S_DB2 + c] = s;
+  if (t < 16) {
+    float s_ = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) s_ += scr_b1[w * 16 + t];
+    slab[S_DB1 + t] = s_;
+  } else if (t >= 64 && t < 96) {
+    float s_ = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) s_ += scr_b2[w * 32 + t - 64];
+    slab[S_DB2 + t - 64] = s_;
+  } else if (t >= 128 && t < 130) {
+    slab[S_PAD + t - 128] = 0.f;
   }
 }
 
@@ -414,7 +587,8 @@ __global__ __launch_bounds__(1024) void dcnn_slab_sum(const float* __restrict__ 
       if (!k.want_grad) return;
       if (i == S_DBFC) k.dbfc[0] = tsum;
       else if (i < S_DB2) k.db1[i - S_DB1] = tsum;
-      else if (i < S_DW1) k.db2[i - S_DB2] = tsum;
+      else if (i < S_PAD) k.db2[i - S_DB2] = tsum;
+      else if (i < S_DW1) return;
       else if (i < S_DW2) k.dw1[i - S_DW1] = tsum;
       else if (i < S_DWFC) k.dw2[i - S_DW2] = tsum;
       else {                                       // slab: k' = pix*32 + c   ->   torch: c*P + pix
@@ -427,8 +601,20 @@ __global__ __launch_bounds__(1024) void dcnn_slab_sum(const float* __restrict__ 
 }
 
 
+template <int T>
+void launch_fused(int nb, size_t lds, hipStream_t s, const float* xa, int bsplit, const float* p0, const float* p1, int B,
+                  float ya, float yb, const __bf16* pack, float* logits, float* slabs, int width, int want_grad) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)dcnn_fused_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((dcnn_fused_kernel<T>), dim3(nb), dim3(NTHREADS), lds, s, xa, bsplit, p0, p1, B, ya, yb, pack, logits,
+                     slabs, width, want_grad);
+}
+
 inline size_t lds_bytes(const Dims& d) {
-  return (size_t)(d.xs_elems() + d.h1_elems() + d.d2_elems() + W_ELEMS) * 2 + 64 * sizeof(float);
+  return (size_t)(d.xs_elems() + d.h1_elems() + d.d2_elems() + W_ELEMS) * 2 + (64 + 64) * sizeof(float);
 }
 // One persistent workgroup per CU (151 KB of LDS each) -- on 7/8 of the CUs: a workgroup of this kernel owns its CU's
 // LDS, so nothing else can run beside it there; the training step runs the generators' latency-bound launches on
@@ -452,6 +638,8 @@ inline int slab_width(const Dims& d, int want_grad) { return want_grad ? S_DWFC 
 inline bool supported(int T) {
   if (T < 8 || T % 2) return false;   // even T: the channel-interleaved input rows stay 8-byte aligned
   const Dims d(T);
+  // kernel instances exist for the six even roll lengths with OW2 in {4, 8, 12}: 16, 18, 32, 34, 48, 50
+  if (T != 16 && T != 18 && T != 32 && T != 34 && T != 48 && T != 50) return false;
   return d.OW2 >= 4 && d.OW2 <= 16 && d.OW2 % 4 == 0 && d.KFC <= 8 * NTHREADS * 3 && (OH2 * d.G2) % 8 == 0 &&
          (OH1 * d.G1) % 8 == 0 && lds_bytes(d) <= 160 * 1024 && (size_t)(4096 + 2048 + 4096) * 4 <= lds_bytes(d);
 }
@@ -491,35 +679,33 @@ extern "C" int gdm_dcnn_fused(const float* xa, int bsplit, const float* p0, cons
   GDM_REQUIRE(bsplit >= 0 && bsplit <= B && (bsplit == 0 || xa) && (bsplit == B || (p0 && p1)),
               "gdm_dcnn_fused: input pointers do not cover the batch");
   GDM_REQUIRE(!want_grad || (dw1 && db1 && dw2 && db2 && dwfc && dbfc), "gdm_dcnn_fused: gradient outputs missing");
+  GDM_REQUIRE(((uintptr_t)workspace & 15) == 0, "gdm_dcnn_fused: workspace must be 16-byte aligned");
   if (!workspace || workspace_bytes < gdm_dcnn_fused_workspace_bytes(B, T, want_grad)) {
     gdm_set_error("gdm_dcnn_fused: workspace too small");
     return GDM_EWORKSPACE;
   }
   const Dims d(T);
   hipStream_t s = (hipStream_t)stream;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)dcnn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
   const int nb = n_blocks(B), width = slab_width(d, want_grad);
   float* slabs = (float*)workspace;
-  hipLaunchKernelGGL(dcnn_fused_kernel, dim3(nb), dim3(NTHREADS), lds_bytes(d), s, xa, bsplit, p0, p1, B, T, ya, yb,
-                     (const __bf16*)pack, logits, slabs, width, want_grad);
-  float* scratch = slabs + (size_t)nb * width;      // up to 64 group partials
-  const int groups = nb <= 32 ? 1 : (nb + 31) / 32;
-  const int per = (nb + groups - 1) / groups;
+  switch (T) {
+#define GDM_DCNN_CASE(TT)                                                                                               \
+    case TT:                                                                                                            \
+      launch_fused<TT>(nb, lds_bytes(d), s, xa, bsplit, p0, p1, B, ya, yb, (const __bf16*)pack, logits, slabs, width,     \
+                       want_grad);                                                                                      \
+      break;
+    GDM_DCNN_CASE(16) GDM_DCNN_CASE(18) GDM_DCNN_CASE(32) GDM_DCNN_CASE(34) GDM_DCNN_CASE(48) GDM_DCNN_CASE(50)
+#undef GDM_DCNN_CASE
+    default:
+      gdm_set_error("gdm_dcnn_fused: no kernel instance for this roll length");
+      return GDM_EINVAL;
+  }
+  // one level: 64 columns x 16 waves per block, wave w adds slabs w, w+16, ... (fixed order); a two-level tree was two
+  // dependent launches for the same 14-21 MB of reads
   const unsigned gx = (unsigned)((width + 63) / 64);
   const DcnnSinks sinks{loss, accumulate_loss, want_grad, dw1, db1, dw2, db2, dwfc, dbfc, T};
-  if (groups == 1) {
-    hipLaunchKernelGGL(dcnn_slab_sum<true>, dim3(gx, 1), dim3(1024), 0, s, (const float*)slabs, nb, per, width,
-                       (float*)nullptr, sinks);
-  } else {
-    hipLaunchKernelGGL(dcnn_slab_sum<false>, dim3(gx, groups), dim3(1024), 0, s, (const float*)slabs, nb, per, width,
-                       scratch, sinks);
-    hipLaunchKernelGGL(dcnn_slab_sum<true>, dim3(gx, 1), dim3(1024), 0, s, (const float*)scratch, groups, groups, width,
-                       (float*)nullptr, sinks);
-  }
+  hipLaunchKernelGGL(dcnn_slab_sum<true>, dim3(gx, 1), dim3(1024), 0, s, (const float*)slabs, nb, nb, width,
+                     (float*)nullptr, sinks);
   GDM_LAUNCH_OK("gdm_dcnn_fused");
   return GDM_OK;
 }

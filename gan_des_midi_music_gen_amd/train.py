@@ -628,12 +628,22 @@ class MmganTrainer(_TrainerBase):
         # (a branch forked at the very root of a captured graph was observed to run before, not beside, the main
         # branch: fork after a first small launch on the main stream)
         self.d.extra[1:4].zero_()
-        for sd in sides:
-            sd.wait_stream(main)
-        g1, g2, g1b, g2b = self._generators_forward_both(noise1, noise2, beats, g1_in_a, g1_in_b, sides)
-        self.last_g1, self.last_g2 = g1, g2
-        self._gen_b = (g1b, g2b)           # second forward's outputs: the bridge of the generator step consumes them
-        if callable(fake_a):
+
+        def generators():
+            for sd in sides:
+                sd.wait_stream(torch.cuda.current_stream())
+            g1, g2, g1b, g2b = self._generators_forward_both(noise1, noise2, beats, g1_in_a, g1_in_b, sides)
+            self.last_g1, self.last_g2 = g1, g2
+            self._gen_b = (g1b, g2b)       # second forward's outputs: the bridge of the generator step consumes them
+            return g1, g2
+
+        # A callable bridge needs the generators' output first.  With tensor stand-ins nothing in the iteration reads
+        # it, and the chain is forked AFTER the discriminator kernel's launch: that kernel owns the LDS of every CU it
+        # runs on, so generator launches beside it only wait for CUs; behind it they fill the small-kernel stretch of
+        # the iteration (slab sums, Adam, re-pack).
+        gen_late = not callable(fake_a)
+        if not gen_late:
+            g1, g2 = generators()
             for sd in sides:
                 main.wait_stream(sd)
             fake_a = fake_a(g1, g2)
@@ -645,7 +655,11 @@ class MmganTrainer(_TrainerBase):
             # batch [fake ; real] with labels 0 / 1 (304-305); real_data is read as two planes: no stack/permute copy
             ops.dcnn_fused(fa, (Fn._f32c(piano_roll), Fn._f32c(durations)), t, 0.0, 1.0, self._pack,
                            loss_out=self.loss_d, grad_out=gv)
+            if gen_late:
+                generators()
         else:
+            if gen_late:
+                generators()
             x = torch.empty((2 * b, 2) + tuple(piano_roll.shape[1:]), dtype=torch.float32, device=dev)
             x[:b].copy_(fake_a)                        # [fake ; real]: same order as the two loss terms (304-305)
             x[b:, 0].copy_(piano_roll)                 # real_data = stack([roll, dur]).permute(1,0,2,3) (290)
@@ -658,8 +672,12 @@ class MmganTrainer(_TrainerBase):
             grads = Fn.dcnn_backward(saved, dl, w2, wf, dt)[:6]
             for gview, g in zip(gv, grads):
                 gview.copy_(g.view(gview.shape))
-        for sd in sides:
-            main.wait_stream(sd)
+        # one rank: the late generator chains are joined at the end of the iteration (_part_b); with more ranks this
+        # piece is a graph of its own and has to join its branches itself
+        self._gen_join_pending = gen_late and self.world == 1
+        if not self._gen_join_pending:
+            for sd in sides:
+                main.wait_stream(sd)
 
     def _part_b(self, piano_roll, beats, noise1, noise2, fake_b, g1_in_b):
         """Adam (308), then the "G" step (311-315): D forward on the bridge's output for the generators' second forward
@@ -689,6 +707,11 @@ class MmganTrainer(_TrainerBase):
             else:
                 _, dlg = ops.bce_with_logits(logits_g.view(-1), 1.0, loss_out=self.loss_g)
                 Fn.dcnn_backward(saved_g, dlg, w2, wf, dt)     # dead values (only D's .grad in the reference)
+        if getattr(self, "_gen_join_pending", False):
+            main = torch.cuda.current_stream()
+            for sd in self._sides(piano_roll.device):
+                main.wait_stream(sd)
+            self._gen_join_pending = False
 
     # ---- hipGraph capture for fixed input buffers --------------------------------------------------------------------
     def capture(self, piano_roll, durations, beats, noise1, noise2, fake_a, fake_b, g1_in_a, g1_in_b):

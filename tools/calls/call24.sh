@@ -1,0 +1,3 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+B=512 python tools/bench_gemm.py 2>&1 | grep -v Warn
+B=256 python tools/bench_gemm.py 2>&1 | grep -v Warn | head -3
