@@ -15,6 +15,18 @@ ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
 _c = ctypes
 _P, _I, _L, _F, _Z = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
 
+class LinearBnJob(_c.Structure):
+    """gdm_linear_bn_job (include/gdm.h)."""
+    _fields_ = [(n, _P) for n in ("x", "w", "bias", "gamma", "beta", "running_mean", "running_var",
+                                  "num_batches_tracked", "y_out", "out", "save_mean", "save_invstd")] + \
+               [(n, _I) for n in ("M", "N", "K", "groups", "stat_repeats")]
+
+
+class ConcatJob(_c.Structure):
+    """gdm_concat_job (include/gdm.h)."""
+    _fields_ = [("a", _P), ("b", _P), ("out", _P), ("M", _I), ("Ka", _I), ("Kb", _I)]
+
+
 # name -> (restype, argtypes); must list every function declared in include/gdm.h (tests/test_abi.py checks that)
 SIGNATURES = {
     "gdm_last_error": (_c.c_char_p, []),
@@ -60,6 +72,8 @@ SIGNATURES = {
     "gdm_simnn_head_workspace_bytes": (_Z, [_I]),
     "gdm_simnn_head": (_I, [_P, _P, _P, _I, _I, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "gdm_linear_bn_act_max_rows": (_I, []),
+    "gdm_linear_bn_act_fwd_multi": (_I, [_P, _I, _F, _F, _I, _I, _P]),
+    "gdm_concat_cols_multi": (_I, [_P, _I, _P]),
     "gdm_linear_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I,
                                    _P]),
     "gdm_dcnn_fused_supported": (_I, [_I]),

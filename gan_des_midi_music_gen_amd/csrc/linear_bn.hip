@@ -19,19 +19,33 @@ constexpr int LB_M = 256, LB_N = 32, LB_KT = 32, LB_LD = LB_KT + 8;
 // 4-7 group g+1 through the same barriers (the launch is a latency chain -- staging, MFMA, two reduction rounds, stores --
 // so two groups one after the other cost twice the launch, side by side barely more than one); the running statistics
 // still take the groups' updates in order, applied by the first group's threads once both batches' statistics are in LDS.
+// Up to two independent blocks ("jobs": different inputs, weights and shapes) share one launch -- the workgroups
+// [0, tiles0) belong to job 0, the rest to job 1: model 2's two generators have the same depth, so their k-th blocks
+// go out together and an iteration's generator work is 4 launches instead of 8.
+struct LbJobs {
+  gdm_linear_bn_job j[2];
+  int tiles0;
+};
+
 template <bool VEC, int GP>
-__global__ __launch_bounds__(256 * GP) void linear_bn_act_kernel(const float* x, const float* __restrict__ w,
-                                                            const float* __restrict__ bias,
-                                                            const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta,
-                                                            float* __restrict__ running_mean,
-                                                            float* __restrict__ running_var,
-                                                            int64_t* __restrict__ nbt, float momentum, float eps,
-                                                            int act, int training, int M, int N, int K,
-                                                            float* y_out, float* out,
-                                                            float* __restrict__ save_mean,
-                                                            float* __restrict__ save_invstd, int groups,
-                                                            int stat_repeats) {
+__global__ __launch_bounds__(256 * GP) void linear_bn_act_kernel(LbJobs jobs, float momentum, float eps, int act,
+                                                                 int training) {
+  const int job = (int)blockIdx.x >= jobs.tiles0 ? 1 : 0;
+  const gdm_linear_bn_job& jb = jobs.j[job];
+  const int tile = (int)blockIdx.x - (job ? jobs.tiles0 : 0);
+  const float* x = jb.x;
+  const float* __restrict__ w = jb.w;
+  const float* __restrict__ bias = jb.bias;
+  const float* __restrict__ gamma = jb.gamma;
+  const float* __restrict__ beta = jb.beta;
+  float* __restrict__ running_mean = jb.running_mean;
+  float* __restrict__ running_var = jb.running_var;
+  int64_t* __restrict__ nbt = jb.num_batches_tracked;
+  const int M = jb.M, N = jb.N, K = jb.K, groups = jb.groups, stat_repeats = jb.stat_repeats;
+  float* y_out = jb.y_out;
+  float* out = jb.out;
+  float* __restrict__ save_mean = jb.save_mean;
+  float* __restrict__ save_invstd = jb.save_invstd;
   __shared__ __attribute__((aligned(16))) __bf16 As_[GP][2][LB_M * LB_LD];     // [group slot][hi | lo]
   __shared__ __attribute__((aligned(16))) __bf16 Bs_[GP][2][LB_N * LB_LD];
   __shared__ float colred_[GP][4][LB_N];
@@ -41,8 +55,8 @@ __global__ __launch_bounds__(256 * GP) void linear_bn_act_kernel(const float* x,
   auto& Bs = Bs_[gsel];
   auto& colred = colred_[gsel];
   auto& colstat = colstat_[gsel];
-  const int n0 = blockIdx.x * LB_N;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && training && nbt) nbt[0] += (int64_t)groups * stat_repeats;
+  const int n0 = tile * LB_N;
+  if (tile == 0 && threadIdx.x == 0 && training && nbt) nbt[0] += (int64_t)groups * stat_repeats;
   // `groups` independent batches of M rows share the weights and are normalised with their OWN batch statistics, one
   // after the other (a generator's two forwards of one training iteration, network_tests.py:294 and 312, in one launch:
   // the running statistics take the updates in that order); `stat_repeats` applies a group's running-statistics update
@@ -253,26 +267,48 @@ __global__ __launch_bounds__(256 * GP) void linear_bn_act_kernel(const float* x,
 
 extern "C" int gdm_linear_bn_act_max_rows(void) { return LB_M; }
 
+namespace {
+int launch_jobs(const gdm_linear_bn_job* jobs, int n_jobs, float momentum, float eps, int act, int training,
+                hipStream_t s, const char* who) {
+  LbJobs lj{};
+  bool vec = true;
+  int gp = 1, tiles = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const gdm_linear_bn_job& j = jobs[i];
+    GDM_REQUIRE(j.x && j.w && j.gamma && j.beta && j.out && j.save_mean && j.save_invstd, "%s: null pointer", who);
+    GDM_REQUIRE(j.groups >= 1 && j.stat_repeats >= 1, "%s: groups and stat_repeats must be >= 1", who);
+    GDM_REQUIRE(j.M >= 1 && j.M <= LB_M && j.N >= 1 && j.K >= 1, "%s: M=%d outside 1..%d (or bad N/K)", who, j.M, LB_M);
+    GDM_REQUIRE(!training || j.M > 1, "%s: training-mode batch norm needs more than 1 row", who);
+    GDM_REQUIRE(training || (j.running_mean && j.running_var), "%s: eval mode needs running statistics", who);
+    vec = vec && (j.K % 4 == 0) && ((((uintptr_t)j.x | (uintptr_t)j.w) & 15) == 0);
+    if (j.groups >= 2) gp = 2;
+    lj.j[i] = j;
+    if (i == 0) lj.tiles0 = (j.N + LB_N - 1) / LB_N;
+    tiles += (j.N + LB_N - 1) / LB_N;
+  }
+  const dim3 grid(tiles);
+#define GDM_LB_LAUNCH(VEC_, GP_)                                                                                          \
+  hipLaunchKernelGGL((linear_bn_act_kernel<VEC_, GP_>), grid, dim3(256 * GP_), 0, s, lj, momentum, eps, act, training)
+  if (gp == 2) { if (vec) GDM_LB_LAUNCH(true, 2); else GDM_LB_LAUNCH(false, 2); }
+  else { if (vec) GDM_LB_LAUNCH(true, 1); else GDM_LB_LAUNCH(false, 1); }
+#undef GDM_LB_LAUNCH
+  GDM_LAUNCH_OK(who);
+  return GDM_OK;
+}
+}  // namespace
+
 extern "C" int gdm_linear_bn_act_fwd(const float* x, const float* w, const float* bias, const float* gamma,
                                      const float* beta, float* running_mean, float* running_var,
                                      int64_t* num_batches_tracked, float momentum, float eps, int act, int training,
                                      int M, int N, int K, float* y_out, float* out, float* save_mean,
                                      float* save_invstd, int groups, int stat_repeats, void* stream) {
-  GDM_REQUIRE(x && w && gamma && beta && out && save_mean && save_invstd, "gdm_linear_bn_act_fwd: null pointer");
-  GDM_REQUIRE(groups >= 1 && stat_repeats >= 1, "gdm_linear_bn_act_fwd: groups and stat_repeats must be >= 1");
-  GDM_REQUIRE(M >= 1 && M <= LB_M && N >= 1 && K >= 1, "gdm_linear_bn_act_fwd: M=%d outside 1..%d (or bad N/K)", M, LB_M);
-  GDM_REQUIRE(!training || M > 1, "gdm_linear_bn_act_fwd: training-mode batch norm needs more than 1 row");
-  GDM_REQUIRE(training || (running_mean && running_var), "gdm_linear_bn_act_fwd: eval mode needs running statistics");
-  const bool vec = (K % 4 == 0) && ((((uintptr_t)x | (uintptr_t)w) & 15) == 0);
-  const dim3 grid((N + LB_N - 1) / LB_N);
-  hipStream_t s = (hipStream_t)stream;
-#define GDM_LB_LAUNCH(VEC_, GP_)                                                                                          \
-  hipLaunchKernelGGL((linear_bn_act_kernel<VEC_, GP_>), grid, dim3(256 * GP_), 0, s, x, w, bias, gamma, beta, running_mean, \
-                     running_var, num_batches_tracked, momentum, eps, act, training, M, N, K, y_out, out, save_mean,       \
-                     save_invstd, groups, stat_repeats)
-  if (groups >= 2) { if (vec) GDM_LB_LAUNCH(true, 2); else GDM_LB_LAUNCH(false, 2); }
-  else { if (vec) GDM_LB_LAUNCH(true, 1); else GDM_LB_LAUNCH(false, 1); }
-#undef GDM_LB_LAUNCH
-  GDM_LAUNCH_OK("gdm_linear_bn_act_fwd");
-  return GDM_OK;
+  const gdm_linear_bn_job j{x, w, bias, gamma, beta, running_mean, running_var, num_batches_tracked, y_out, out,
+                            save_mean, save_invstd, M, N, K, groups, stat_repeats};
+  return launch_jobs(&j, 1, momentum, eps, act, training, (hipStream_t)stream, "gdm_linear_bn_act_fwd");
+}
+
+extern "C" int gdm_linear_bn_act_fwd_multi(const gdm_linear_bn_job* jobs, int n_jobs, float momentum, float eps, int act,
+                                           int training, void* stream) {
+  GDM_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= 2, "gdm_linear_bn_act_fwd_multi: 1 or 2 jobs per launch");
+  return launch_jobs(jobs, n_jobs, momentum, eps, act, training, (hipStream_t)stream, "gdm_linear_bn_act_fwd_multi");
 }

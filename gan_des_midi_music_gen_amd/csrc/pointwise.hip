@@ -771,3 +771,36 @@ extern "C" int gdm_simnn_head(const float* h1, const float* w2, const float* b2,
   GDM_LAUNCH_OK("gdm_simnn_head");
   return GDM_OK;
 }
+
+// ---- concatenation along dim 1 for a few small jobs in one launch (the generators' inputs of model 2) -----------------
+namespace {
+struct ConcatJobs {
+  gdm_concat_job j[4];
+  int n;
+};
+__global__ __launch_bounds__(256) void concat_cols_kernel(ConcatJobs js) {
+  const gdm_concat_job& q = js.j[blockIdx.y];
+  const int K = q.Ka + q.Kb, total = q.M * K;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int m = i / K, k = i - m * K;
+    q.out[i] = k < q.Ka ? q.a[(size_t)m * q.Ka + k] : q.b[(size_t)m * q.Kb + (k - q.Ka)];
+  }
+}
+}  // namespace
+
+extern "C" int gdm_concat_cols_multi(const gdm_concat_job* jobs, int n_jobs, void* stream) {
+  GDM_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= 4, "gdm_concat_cols_multi: 1..4 jobs per launch");
+  ConcatJobs js{};
+  js.n = n_jobs;
+  int most = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const gdm_concat_job& q = jobs[i];
+    GDM_REQUIRE(q.a && q.out && q.M >= 1 && q.Ka >= 1 && q.Kb >= 0 && (q.b || q.Kb == 0), "gdm_concat_cols_multi: bad job %d", i);
+    js.j[i] = q;
+    most = q.M * (q.Ka + q.Kb) > most ? q.M * (q.Ka + q.Kb) : most;
+  }
+  const int bx = (most + 255) / 256 < 64 ? (most + 255) / 256 : 64;
+  hipLaunchKernelGGL(concat_cols_kernel, dim3(bx, n_jobs), dim3(256), 0, (hipStream_t)stream, js);
+  GDM_LAUNCH_OK("gdm_concat_cols_multi");
+  return GDM_OK;
+}

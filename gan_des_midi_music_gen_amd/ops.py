@@ -517,6 +517,57 @@ def linear_bn_act_fwd(x, w, bias, gamma, beta, running_mean, running_var, nbt, *
     return out, y, mean, invstd
 
 
+def linear_bn_act_fwd_multi(jobs, *, act, training=True, momentum=0.1, eps=1e-5):
+    """1 or 2 independent Linear+BatchNorm1d+activation blocks in ONE launch.  jobs: list of dicts with the positional
+    arguments of linear_bn_act_fwd (x, w, bias, gamma, beta, running_mean, running_var, nbt) and optional groups /
+    stat_repeats.  Returns [(out, save_mean, save_invstd)] per job (forward only)."""
+    assert 1 <= len(jobs) <= 2
+    arr = (_lib.LinearBnJob * len(jobs))()
+    res = []
+    for i, j in enumerate(jobs):
+        x, w = j["x"], j["w"]
+        _need_gpu(x, w, j["bias"], j["gamma"], j["beta"], j["running_mean"], j["running_var"], j["nbt"])
+        assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1] and x.is_contiguous() and w.is_contiguous()
+        assert x.dtype == torch.float32 and w.dtype == torch.float32
+        groups, reps = int(j.get("groups", 1)), int(j.get("stat_repeats", 1))
+        rows, k = x.shape
+        assert rows % groups == 0
+        n = w.shape[0]
+        out = torch.empty((rows, n), dtype=torch.float32, device=x.device)
+        shape = (n,) if groups == 1 else (groups, n)
+        mean = torch.empty(shape, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(shape, dtype=torch.float32, device=x.device)
+        a = arr[i]
+        a.x, a.w, a.bias, a.gamma, a.beta = _p(x), _p(w), _p(j["bias"]), _p(j["gamma"]), _p(j["beta"])
+        a.running_mean, a.running_var, a.num_batches_tracked = _p(j["running_mean"]), _p(j["running_var"]), _p(j["nbt"])
+        a.y_out, a.out, a.save_mean, a.save_invstd = None, _p(out), _p(mean), _p(invstd)
+        a.M, a.N, a.K, a.groups, a.stat_repeats = rows // groups, n, k, groups, reps
+        res.append((out, mean, invstd))
+    _call("gdm_linear_bn_act_fwd_multi", ctypes.cast(arr, ctypes.c_void_p), len(jobs), float(momentum), float(eps), act,
+          1 if training else 0, _stream())
+    return res
+
+
+def concat_cols_multi(pairs, outs=None):
+    """[torch.cat((a, b), dim=1) for a, b in pairs] for up to four small fp32 pairs in ONE launch (``outs``: contiguous
+    destination tensors, e.g. row blocks of one buffer)."""
+    assert 1 <= len(pairs) <= 4 and (outs is None or len(outs) == len(pairs))
+    arr = (_lib.ConcatJob * len(pairs))()
+    res = []
+    for i, (a, b) in enumerate(pairs):
+        _need_gpu(a, b)
+        assert a.dim() == 2 and b.dim() == 2 and a.shape[0] == b.shape[0] and a.is_contiguous() and b.is_contiguous()
+        assert a.dtype == torch.float32 and b.dtype == torch.float32
+        shape = (a.shape[0], a.shape[1] + b.shape[1])
+        out = outs[i] if outs is not None else torch.empty(shape, dtype=torch.float32, device=a.device)
+        assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == torch.float32
+        q = arr[i]
+        q.a, q.b, q.out, q.M, q.Ka, q.Kb = _p(a), _p(b), _p(out), a.shape[0], a.shape[1], b.shape[1]
+        res.append(out)
+    _call("gdm_concat_cols_multi", ctypes.cast(arr, ctypes.c_void_p), len(pairs), _stream())
+    return res
+
+
 def dcnn_fused_supported(t):
     return bool(_lib.load().gdm_dcnn_fused_supported(int(t)))
 

@@ -522,10 +522,29 @@ class MmganTrainer(_TrainerBase):
         d = mmgan.discriminator
         self._init_common([d.conv1.weight, d.conv1.bias, d.conv2.weight, d.conv2.bias, d.fc.weight, d.fc.bias], lr,
                           betas, eps, compute_dtype, elide_dead_backward, process_group)
-        self.last_g1 = self.last_g2 = None
+        self._last_g1 = self._last_g2 = None
         self._pack = None          # packed weight images of the fused discriminator kernel (persistent buffer)
         self._graph = None
+        self._graph_gen = None     # one rank: the generators' launches as a graph of their own (see capture)
+        self._gen_event = None     # recorded behind the last replay of that graph
         self._gen_stream = None
+        self._gen_replay_stream = None
+
+    # The generators' outputs of the last iteration.  After ``replay`` on one rank they are produced on a stream of the
+    # trainer's own: reading them here makes the CURRENT stream wait for that stream's last replay.
+    def _join_generators(self):
+        if self._gen_event is not None and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream().wait_event(self._gen_event)
+
+    @property
+    def last_g1(self):
+        self._join_generators()
+        return self._last_g1
+
+    @property
+    def last_g2(self):
+        self._join_generators()
+        return self._last_g2
 
     def invalidate_weights(self):
         self._pack = None
@@ -579,14 +598,27 @@ class MmganTrainer(_TrainerBase):
             g1_in_a = torch.randn(b, mm.generator1.input_tensor_dim).to(noise1.device)
         if g1_in_b is None:
             g1_in_b = torch.randn(b, mm.generator1.input_tensor_dim).to(noise1.device)
-        s1, s2 = streams if streams is not None else (None, None)
+        s1 = streams[0] if streams is not None else None
+        l1, l2 = self._layers(mm.generator1), self._layers(mm.generator2)
         with torch.cuda.stream(s1 if s1 is not None else torch.cuda.current_stream()):
-            x1 = torch.cat((torch.cat((noise1, g1_in_a), dim=1), torch.cat((noise1, g1_in_b), dim=1)), dim=0)
-            o1, _ = Fn.mlp_bn_sigmoid_forward(x1, self._layers(mm.generator1), True, dt, need_backward=False, groups=2)
-        with torch.cuda.stream(s2 if s2 is not None else torch.cuda.current_stream()):
-            x2 = torch.cat((noise2, beats), dim=1)
-            o2, _ = Fn.mlp_bn_sigmoid_forward(x2, self._layers(mm.generator2), True, dt, need_backward=False,
-                                              stat_repeats=2)
+            # the three input concatenations in one launch, then the k-th blocks of BOTH generators in one launch
+            # (same depth, independent): 5 launches for an iteration's generator work
+            n1, n2, bt = Fn._f32c(noise1), Fn._f32c(noise2), Fn._f32c(beats)
+            ia, ib = Fn._f32c(g1_in_a), Fn._f32c(g1_in_b)
+            x1 = torch.empty((2 * b, n1.shape[1] + ia.shape[1]), dtype=torch.float32, device=n1.device)
+            x2 = torch.empty((b, n2.shape[1] + bt.shape[1]), dtype=torch.float32, device=n1.device)
+            ops.concat_cols_multi([(n1, ia), (n1, ib), (n2, bt)], outs=[x1[:b], x1[b:], x2])
+            if len(l1) == len(l2):
+                for (w1_, b1_, g1_, be1_, rm1, rv1, nb1), (w2_, b2_, g2_, be2_, rm2, rv2, nb2) in zip(l1, l2):
+                    (x1, _, _), (x2, _, _) = ops.linear_bn_act_fwd_multi(
+                        [dict(x=x1, w=w1_, bias=b1_, gamma=g1_, beta=be1_, running_mean=rm1, running_var=rv1, nbt=nb1,
+                              groups=2),
+                         dict(x=x2, w=w2_, bias=b2_, gamma=g2_, beta=be2_, running_mean=rm2, running_var=rv2, nbt=nb2,
+                              stat_repeats=2)], act=ops.ACT_SIGMOID, training=True)
+                o1, o2 = x1, x2
+            else:
+                o1, _ = Fn.mlp_bn_sigmoid_forward(x1, l1, True, dt, need_backward=False, groups=2)
+                o2, _ = Fn.mlp_bn_sigmoid_forward(x2, l2, True, dt, need_backward=False, stat_repeats=2)
         a = mm.generator1.adj_size
         g1 = o1.view(2, b, -1, a[0], a[1])
         return g1[0], o2, g1[1], o2
@@ -610,10 +642,11 @@ class MmganTrainer(_TrainerBase):
             self._gen_stream = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
         return self._gen_stream
 
-    def _part_a(self, piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a, g1_in_b):
+    def _part_a(self, piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a, g1_in_b, with_generators=True):
         """D step up to the gradient (network_tests.py:293-307): the generators (both forwards of the iteration, see
         _generators_forward_both) on side streams beside the discriminator's forward + loss + backward; every branch
-        is joined before returning."""
+        is joined before returning (one rank: at the end of ``_part_b``).  ``with_generators=False`` leaves the
+        generators out (``capture`` records them as a graph of their own)."""
         dt = self.dt
         w1, b1, w2, b2, wf, bf = self.d.views
         gv = self.d.grad_views
@@ -633,7 +666,7 @@ class MmganTrainer(_TrainerBase):
             for sd in sides:
                 sd.wait_stream(torch.cuda.current_stream())
             g1, g2, g1b, g2b = self._generators_forward_both(noise1, noise2, beats, g1_in_a, g1_in_b, sides)
-            self.last_g1, self.last_g2 = g1, g2
+            self._last_g1, self._last_g2 = g1, g2
             self._gen_b = (g1b, g2b)       # second forward's outputs: the bridge of the generator step consumes them
             return g1, g2
 
@@ -642,7 +675,9 @@ class MmganTrainer(_TrainerBase):
         # runs on, so generator launches beside it only wait for CUs; behind it they fill the small-kernel stretch of
         # the iteration (slab sums, Adam, re-pack).
         gen_late = not callable(fake_a)
-        if not gen_late:
+        if not with_generators:
+            gen_late = False
+        elif not gen_late:
             g1, g2 = generators()
             for sd in sides:
                 main.wait_stream(sd)
@@ -675,7 +710,7 @@ class MmganTrainer(_TrainerBase):
         # one rank: the late generator chains are joined at the end of the iteration (_part_b); with more ranks this
         # piece is a graph of its own and has to join its branches itself
         self._gen_join_pending = gen_late and self.world == 1
-        if not self._gen_join_pending:
+        if with_generators and not self._gen_join_pending:
             for sd in sides:
                 main.wait_stream(sd)
 
@@ -735,10 +770,23 @@ class MmganTrainer(_TrainerBase):
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
         if self.world == 1:
+            # TWO graphs without a single fork or join: the discriminator chain (zero, kernel, slab sum, Adam, re-pack,
+            # kernel, slab sum) and the generators' eight launches.  Inside one multi-branch graph every edge between
+            # branches became a cross-queue dependency on the GPU: 20-35 us each on the discriminator chain (66 us
+            # of a 174-us iteration were such gaps).  ``replay`` starts the generator graph on a stream of the
+            # trainer's own, ordered behind the previous iteration's discriminator graph, and never makes the
+            # discriminator chain wait for it (``last_g1`` / ``last_g2`` wait when they are read).
+            self._graph_gen = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_gen):
+                g1, g2, g1b, g2b = self._generators_forward_both(noise1, noise2, beats, g1_in_a, g1_in_b, None)
+                self._last_g1, self._last_g2 = g1, g2
+                self._gen_b = (g1b, g2b)
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
-                self.step(*args[:7], g1_in_a=g1_in_a, g1_in_b=g1_in_b)
-            self.iterations -= 1
+                self._part_a(piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a, g1_in_b,
+                             with_generators=False)
+                self._part_b(piano_roll, beats, noise1, noise2, fake_b, g1_in_b)
+            self._gen_replay_stream = torch.cuda.Stream(piano_roll.device)
         else:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
@@ -757,6 +805,11 @@ class MmganTrainer(_TrainerBase):
             self._reduce()
             self._graph[1].replay()
         else:
+            sg = self._gen_replay_stream
+            sg.wait_stream(torch.cuda.current_stream())     # behind the previous iteration's discriminator graph
+            with torch.cuda.stream(sg):
+                self._graph_gen.replay()
+                self._gen_event = sg.record_event()
             self._graph.replay()
         self.d.step_count += 1
         self.iterations += 1

@@ -209,7 +209,26 @@ int gdm_simnn_head(const float* h1, const float* w2, const float* b2, int n, int
  * every batch is normalised with its own statistics and the running statistics take the updates in batch order -- the
  * two forwards a generator makes per training iteration (network_tests.py:294, 312) in one launch.  stat_repeats >= 1
  * applies each running-statistics update that many times (a forward repeated on identical inputs).                  */
+typedef struct gdm_linear_bn_job {      /* the arguments of gdm_linear_bn_act_fwd that differ between blocks */
+  const float *x, *w, *bias, *gamma, *beta;
+  float *running_mean, *running_var;
+  int64_t* num_batches_tracked;
+  float *y_out, *out, *save_mean, *save_invstd;
+  int M, N, K, groups, stat_repeats;
+} gdm_linear_bn_job;
 int gdm_linear_bn_act_max_rows(void);
+/* 1 or 2 independent blocks in ONE launch (the k-th blocks of model 2's two generators, network_tests.py:186-187: the
+ * generators have the same depth and do not depend on each other).  Same arithmetic per job as gdm_linear_bn_act_fwd. */
+int gdm_linear_bn_act_fwd_multi(const gdm_linear_bn_job* jobs, int n_jobs, float momentum, float eps, int act,
+                                int training, void* stream);
+/* out_j (M_j, Ka_j + Kb_j) = [a_j | b_j] row by row for up to four jobs in one launch (torch.cat(dim=1) of the
+ * generators' inputs, network_tests.py:87, 119: noise next to the conditioning vector).  b_j may be NULL (copy).   */
+typedef struct gdm_concat_job {
+  const float *a, *b;
+  float* out;
+  int M, Ka, Kb;
+} gdm_concat_job;
+int gdm_concat_cols_multi(const gdm_concat_job* jobs, int n_jobs, void* stream);
 int gdm_linear_bn_act_fwd(const float* x, const float* w, const float* bias, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                           float eps, int act, int training, int M, int N, int K, float* y_out, float* out,

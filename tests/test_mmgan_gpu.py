@@ -293,6 +293,46 @@ def test_stacked_and_repeated_generator_blocks_equal_sequential_launches():
         assert torch.equal(o4, oa) and torch.equal(rm4, rm3) and torch.equal(rv4, rv3) and int(nbt4) == 2
 
 
+def test_two_generator_blocks_in_one_launch_equal_separate_launches():
+    """gdm_linear_bn_act_fwd_multi: the k-th blocks of both generators in one launch == one launch each, bit for bit
+    (different shapes per job, groups=2 beside stat_repeats=2 as the trainer uses them); gdm_concat_cols_multi ==
+    torch.cat(dim=1), also into row blocks of one buffer."""
+    from gan_des_midi_music_gen_amd import ops
+    g = torch.Generator().manual_seed(33)
+    m = 48
+
+    def block(k, n):
+        return dict(w=(torch.randn(n, k, generator=g) * 0.1).to(DEV), bias=torch.randn(n, generator=g).to(DEV),
+                    gamma=(torch.rand(n, generator=g) + 0.5).to(DEV), beta=torch.randn(n, generator=g).to(DEV))
+
+    def fresh(n):
+        return dict(running_mean=torch.zeros(n, device=DEV), running_var=torch.ones(n, device=DEV),
+                    nbt=torch.zeros((), dtype=torch.long, device=DEV))
+
+    for (k1, n1), (k2, n2) in (((100, 256), (100, 256)), ((64, 4096), (64, 20)), ((128, 64), (256, 128))):
+        b1, b2 = block(k1, n1), block(k2, n2)
+        x1 = torch.randn(2 * m, k1, generator=g).to(DEV)
+        x2 = (torch.randn(m, k2, generator=g) * 2 - 1).to(DEV)
+        s1, s2 = fresh(n1), fresh(n2)
+        o1, _, m1, i1 = ops.linear_bn_act_fwd(x1, b1["w"], b1["bias"], b1["gamma"], b1["beta"], s1["running_mean"],
+                                              s1["running_var"], s1["nbt"], act=ops.ACT_SIGMOID, groups=2)
+        o2, _, m2, i2 = ops.linear_bn_act_fwd(x2, b2["w"], b2["bias"], b2["gamma"], b2["beta"], s2["running_mean"],
+                                              s2["running_var"], s2["nbt"], act=ops.ACT_SIGMOID, stat_repeats=2)
+        t1, t2 = fresh(n1), fresh(n2)
+        (p1, pm1, pi1), (p2, pm2, pi2) = ops.linear_bn_act_fwd_multi(
+            [dict(x=x1, groups=2, **b1, **t1), dict(x=x2, stat_repeats=2, **b2, **t2)], act=ops.ACT_SIGMOID)
+        assert torch.equal(p1, o1) and torch.equal(p2, o2)
+        assert torch.equal(pm1, m1) and torch.equal(pi1, i1) and torch.equal(pm2, m2) and torch.equal(pi2, i2)
+        for a, b_ in ((s1, t1), (s2, t2)):
+            assert torch.equal(a["running_mean"], b_["running_mean"]) and torch.equal(a["running_var"], b_["running_var"])
+            assert int(a["nbt"]) == int(b_["nbt"]) == 2
+    a, b_, c = torch.randn(m, 50, generator=g).to(DEV), torch.randn(m, 50, generator=g).to(DEV), torch.randn(m, 7, generator=g).to(DEV)
+    buf = torch.empty(2 * m, 100, device=DEV)
+    outs = ops.concat_cols_multi([(a, b_), (b_, a), (a, c)], outs=[buf[:m], buf[m:], torch.empty(m, 57, device=DEV)])
+    assert torch.equal(buf, torch.cat([torch.cat([a, b_], 1), torch.cat([b_, a], 1)]))
+    assert torch.equal(outs[2], torch.cat([a, c], 1))
+
+
 def test_graph_replay_matches_eager_bf16():
     b = 32
     outs = []
