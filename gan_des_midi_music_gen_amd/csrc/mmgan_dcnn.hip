@@ -50,12 +50,16 @@ __device__ __forceinline__ float leaky(float v) { return v > 0.f ? v : 0.2f * v;
 #ifdef GDM_DCNN_STAMPS
 #define DSTAMP_DECL uint64_t st_last = __builtin_amdgcn_s_memtime(), st_ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int st_n = 0
 #define DSTAMP(k) do { if (threadIdx.x == 0) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); st_ph[k] += now_ - st_last; st_last = now_; } } while (0)
-#define DSTAMP_FLUSH do { if (threadIdx.x == 0 && blockIdx.x == 0) { printf("dcnn stamps (cycles per sample, %d samples):", st_n); \
-  for (int k_ = 0; k_ < 10; ++k_) printf(" P%d=%llu", k_, (unsigned long long)(st_ph[k_] / (st_n > 0 ? st_n : 1))); printf("\n"); } } while (0)
+#define DSTAMP_FLUSH st_last = __builtin_amdgcn_s_memtime()
+#define DSTAMP_END do { if (threadIdx.x == 0 && blockIdx.x == 0) { const uint64_t ep_ = __builtin_amdgcn_s_memtime() - st_last;       \
+  printf("dcnn stamps (cycles per sample, %d samples; P8 = prologue, total):", st_n);                                                \
+  for (int k_ = 0; k_ < 10; ++k_) printf(" P%d=%llu", k_, (unsigned long long)(st_ph[k_] / (k_ != 8 && st_n > 0 ? st_n : 1)));       \
+  printf(" epilogue=%llu\n", (unsigned long long)ep_); } } while (0)
 #else
 #define DSTAMP_DECL
 #define DSTAMP(k)
 #define DSTAMP_FLUSH
+#define DSTAMP_END
 #endif
 
 // ---- weight pack: bf16 images + permuted fc weight + fp32 biases ---------------------------------------------------
@@ -107,6 +111,7 @@ __global__ __launch_bounds__(NTHREADS) void dcnn_fused_kernel(const float* __res
                                                               float* __restrict__ logits, float* __restrict__ slabs,
                                                               int slab_width, int want_grad) {
   constexpr Dims d(T);
+  DSTAMP_DECL;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   __bf16* xs = (__bf16*)dyn_smem;                 // [(H+3)][XWP][2]   index ((r+1)*XWP + (c+1))*2 + ch
   __bf16* h1s = xs + d.xs_elems();                // [(OH1+2)][W1P][16]
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(NTHREADS) void dcnn_fused_kernel(const float* __res
     if (qd < n_chunks) wfc_c[i] = *(const bf16x8*)&wfp[(int64_t)qd * 8];
   }
   if ((int)blockIdx.x < B) x_issue(blockIdx.x);
-  DSTAMP_DECL;
+  DSTAMP(8);                                         // prologue
   const int lr0 = lr, lg0 = lg, q40 = q4, p40 = p4, wv0 = wv;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     // An opaque zero added to the lane coordinates: the phases' (loop-invariant) LDS offsets are then recomputed per
@@ -476,7 +481,10 @@ __global__ __launch_bounds__(NTHREADS) void dcnn_fused_kernel(const float* __res
   // ---- epilogue: one slab per workgroup -------------------------------------------------------------------------------
   float* slab = slabs + (int64_t)blockIdx.x * slab_width;
   if (t == 0) slab[S_LOSS] = loss_acc;
-  if (!want_grad) return;
+  if (!want_grad) {
+    DSTAMP_END;
+    return;
+  }
   if (t == 0) slab[S_DBFC] = dbfc_acc;
   // Everything leaves through LDS (the activation images are dead) so that the slab is written with 16-byte, lane-
   // contiguous stores and the per-channel bias sums are shuffles + an 8-wave sum instead of a 512-step serial loop
@@ -546,6 +554,7 @@ __global__ __launch_bounds__(NTHREADS) void dcnn_fused_kernel(const float* __res
   } else if (t >= 128 && t < 130) {
     slab[S_PAD + t - 128] = 0.f;
   }
+  DSTAMP_END;
 }
 
 // ---- slab reduction + unpack into the torch gradient tensors -----------------------------------------------------------

@@ -509,7 +509,7 @@ class SimnnTrainer(_TrainerBase):
         self._graph_gen = None
         if pipelined and os.environ.get("GDM_EXP_GEN_GRAPH", "1") == "1":
             # The generator forward (6 launches that feed nothing inside the iteration) is a graph of its OWN, replayed
-            # on a stream of the trainer's own behind the previous iteration's main graph: as a branch of the main
+            # on a stream of the trainer's own behind this iteration's main graph (beside the next one): as a branch of the main
             # graph its fork and join were cross-queue dependencies inside the iteration (0.699 -> 0.684 ms).
             # ``last_generated`` waits for that stream when it is read.
             ws, bns = self._gen_state()
@@ -531,13 +531,13 @@ class SimnnTrainer(_TrainerBase):
 
     def replay(self):
         self._sync_hyper()         # lr schedule etc.: the captured Adam reads the device record
+        self._graph.replay()       # the main chain first: its launch never waits for the host's work on the other graph
         if self._graph_gen is not None:
             sg = self._gen_replay_stream
-            sg.wait_stream(torch.cuda.current_stream())     # behind the previous iteration's main graph
+            sg.wait_stream(torch.cuda.current_stream())     # behind this iteration's main graph = beside the next one
             with torch.cuda.stream(sg):
                 self._graph_gen.replay()
                 self._gen_event = sg.record_event()
-        self._graph.replay()
         self.d.step_count += 1
         self.iterations += 1
         return self.loss_d, self.loss_g
@@ -693,9 +693,6 @@ class MmganTrainer(_TrainerBase):
         # discriminator kernels (a generator's second forward follows its first one: BN running statistics)
         main = torch.cuda.current_stream()
         sides = self._sides(dev)
-        # (a branch forked at the very root of a captured graph was observed to run before, not beside, the main
-        # branch: fork after a first small launch on the main stream)
-        self.d.extra[1:4].zero_()
 
         def generators():
             for sd in sides:
@@ -713,6 +710,9 @@ class MmganTrainer(_TrainerBase):
         if not with_generators:
             gen_late = False
         elif not gen_late:
+            # (a branch forked at the very root of a captured graph was observed to run before, not beside, the main
+            # branch: fork after a first small launch on the main stream)
+            self.d.extra[1:4].zero_()
             g1, g2 = generators()
             for sd in sides:
                 main.wait_stream(sd)
@@ -809,8 +809,8 @@ class MmganTrainer(_TrainerBase):
             # kernel, slab sum) and the generators' eight launches.  Inside one multi-branch graph every edge between
             # branches became a cross-queue dependency on the GPU: 20-35 us each on the discriminator chain (66 us
             # of a 174-us iteration were such gaps).  ``replay`` starts the generator graph on a stream of the
-            # trainer's own, ordered behind the previous iteration's discriminator graph, and never makes the
-            # discriminator chain wait for it (``last_g1`` / ``last_g2`` wait when they are read).
+            # trainer's own, ordered behind this iteration's discriminator graph (it runs beside the next one), and
+            # never makes the discriminator chain wait for it (``last_g1`` / ``last_g2`` wait when they are read).
             self._graph_gen = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_gen):
                 g1, g2, g1b, g2b = self._generators_forward_both(noise1, noise2, beats, g1_in_a, g1_in_b, None)
@@ -840,12 +840,12 @@ class MmganTrainer(_TrainerBase):
             self._reduce()
             self._graph[1].replay()
         else:
+            self._graph.replay()   # the discriminator chain first: its launch never waits for the host's work on the other graph
             sg = self._gen_replay_stream
-            sg.wait_stream(torch.cuda.current_stream())     # behind the previous iteration's discriminator graph
+            sg.wait_stream(torch.cuda.current_stream())     # behind this iteration's discriminator graph = beside the next
             with torch.cuda.stream(sg):
                 self._graph_gen.replay()
                 self._gen_event = sg.record_event()
-            self._graph.replay()
         self.d.step_count += 1
         self.iterations += 1
         return self.loss_d, self.loss_g

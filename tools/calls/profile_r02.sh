@@ -17,8 +17,11 @@ python bench.py --no-cpu-baseline --no-roofline --no-graph > gpurun_out/bench_si
 python bench.py --no-cpu-baseline --no-roofline --mode elided > gpurun_out/bench_simnn_elided.json 2>> gpurun_out/bench_default.err
 python bench.py --no-cpu-baseline --no-roofline --no-pipeline > gpurun_out/bench_simnn_nopipeline.json 2>> gpurun_out/bench_default.err
 python bench.py --no-cpu-baseline --dtype fp32 > gpurun_out/bench_simnn_fp32.json 2>> gpurun_out/bench_default.err
-python bench.py --no-cpu-baseline --no-roofline --workload mmgan --no-graph > gpurun_out/bench_mmgan_eager.json 2>> gpurun_out/bench_default.err
+python bench.py --no-cpu-baseline --no-roofline --workload mmgan --no-graph --steps 200 --warmup 20 > gpurun_out/bench_mmgan_eager.json 2>> gpurun_out/bench_default.err
 python bench.py --no-cpu-baseline --no-roofline --workload mmgan --batch 16 > gpurun_out/bench_mmgan_b16.json 2>> gpurun_out/bench_default.err
+rm -rf gpurun_out/tl_mmgan
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl_mmgan -- python bench.py --workload mmgan --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/tl_mmgan.log 2>&1
+python tools/graph_timeline.py gpurun_out/tl_mmgan > gpurun_out/mmgan_replay_timeline.txt
 find gpurun_out -name "*.db" -delete
 grep -h metric gpurun_out/bench_*.json | cut -c1-210
 cat gpurun_out/step_breakdown.txt | head -40

@@ -35,6 +35,7 @@ for name in ("bench_simnn_eager", "bench_simnn_elided", "bench_simnn_nopipeline"
     copy(os.path.join(out, name + ".json"), f"{tag}_{name}.json")
 copy(os.path.join(out, "pytest_gpu_r02.log"), f"{tag}_pytest_gpu.log")
 copy(os.path.join(out, "parity_r02.jsonl"), f"{tag}_parity_measurements.jsonl")
+copy(os.path.join(out, "mmgan_replay_timeline.txt"), f"{tag}_mmgan_replay_timeline.txt")
 copy(os.path.join(out, "r2_ko1.log"), f"{tag}_fused_bwd_knockout.txt")
 copy(os.path.join(out, "r2_overlap.log"), f"{tag}_conv_bwd_side_by_side.txt")
 copy(os.path.join(out, "r2_streams.log"), f"{tag}_stream_concurrency.txt")
