@@ -658,7 +658,12 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
 #pragma unroll
     for (int r = 0; r < 4; ++r) bo[i][r] = bias[8 * lg + 4 * i + r];     // channel map of conv2_fwd_tile
   P1Stage<T, ROWS + 2> sa, sb;
+  // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give every XCD a CONTIGUOUS run of tile
+  // ids per round, so that the tiles that share halo rows / columns (vertical neighbours are n_ctiles ids apart) are
+  // fetched through the same L2.  With tile id = workgroup id every neighbour lived on another XCD and the 1.55x halo
+  // over-read of the 6 x 66 band went to HBM in full (157 MB fetched for 101 MB of p1).
   int u = blockIdx.x;                                       // host guarantees gridDim.x <= n_tiles
+  if ((G & 7) == 0) u = (u & 7) * (G >> 3) + (u >> 3);
   issue(sa, u);
   issue(sb, u + G);
   STAMP(5);
