@@ -509,9 +509,9 @@ class SimnnTrainer(_TrainerBase):
         self._graph_gen = None
         if pipelined and os.environ.get("GDM_EXP_GEN_GRAPH", "1") == "1":
             # The generator forward (6 launches that feed nothing inside the iteration) is a graph of its OWN, replayed
-            # on a stream of the trainer's own behind this iteration's main graph (beside the next one): as a branch of the main
-            # graph its fork and join were cross-queue dependencies inside the iteration (0.699 -> 0.684 ms).
-            # ``last_generated`` waits for that stream when it is read.
+            # on a stream of the trainer's own beside this iteration's main graph: as a branch of the main graph its fork
+            # and join were cross-queue dependencies inside the iteration (0.699 -> 0.684 ms).  The caller's stream waits
+            # for it after the main graph (it is much the shorter one).
             ws, bns = self._gen_state()
             self._graph_gen = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_gen):
@@ -531,13 +531,20 @@ class SimnnTrainer(_TrainerBase):
 
     def replay(self):
         self._sync_hyper()         # lr schedule etc.: the captured Adam reads the device record
-        self._graph.replay()       # the main chain first: its launch never waits for the host's work on the other graph
+        main = torch.cuda.current_stream()
         if self._graph_gen is not None:
+            # behind everything the caller has enqueued so far (its refill of ``noise``, the previous iteration) and
+            # beside this iteration's main graph
             sg = self._gen_replay_stream
-            sg.wait_stream(torch.cuda.current_stream())     # behind this iteration's main graph = beside the next one
+            sg.wait_stream(main)
             with torch.cuda.stream(sg):
                 self._graph_gen.replay()
                 self._gen_event = sg.record_event()
+        self._graph.replay()
+        if self._graph_gen is not None:
+            # whatever the caller enqueues next (a refill of the static inputs, the next replay) comes after the
+            # generator's reads; the generator graph is the shorter one, so this wait is normally already satisfied
+            main.wait_event(self._gen_event)
         self.d.step_count += 1
         self.iterations += 1
         return self.loss_d, self.loss_g
@@ -809,8 +816,8 @@ class MmganTrainer(_TrainerBase):
             # kernel, slab sum) and the generators' eight launches.  Inside one multi-branch graph every edge between
             # branches became a cross-queue dependency on the GPU: 20-35 us each on the discriminator chain (66 us
             # of a 174-us iteration were such gaps).  ``replay`` starts the generator graph on a stream of the
-            # trainer's own, ordered behind this iteration's discriminator graph (it runs beside the next one), and
-            # never makes the discriminator chain wait for it (``last_g1`` / ``last_g2`` wait when they are read).
+            # trainer's own beside this iteration's discriminator graph; the caller's stream waits for it only after
+            # the discriminator chain (the generators' graph is the shorter one).
             self._graph_gen = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_gen):
                 g1, g2, g1b, g2b = self._generators_forward_both(noise1, noise2, beats, g1_in_a, g1_in_b, None)
@@ -840,12 +847,18 @@ class MmganTrainer(_TrainerBase):
             self._reduce()
             self._graph[1].replay()
         else:
-            self._graph.replay()   # the discriminator chain first: its launch never waits for the host's work on the other graph
+            # the generator graph: behind everything the caller has enqueued so far (its refill of the static inputs, the
+            # previous iteration), beside this iteration's discriminator graph
+            main = torch.cuda.current_stream()
             sg = self._gen_replay_stream
-            sg.wait_stream(torch.cuda.current_stream())     # behind this iteration's discriminator graph = beside the next
+            sg.wait_stream(main)
             with torch.cuda.stream(sg):
                 self._graph_gen.replay()
                 self._gen_event = sg.record_event()
+            self._graph.replay()
+            # whatever the caller enqueues next (a refill of the inputs, the next replay) comes after the generators'
+            # reads; their graph is the shorter one, so this wait is normally already satisfied when the chain gets there
+            main.wait_event(self._gen_event)
         self.d.step_count += 1
         self.iterations += 1
         return self.loss_d, self.loss_g

@@ -355,6 +355,39 @@ def test_graph_replay_matches_eager_bf16():
     assert outs[0][3] == outs[1][3] == 10
 
 
+def test_replay_with_refilled_inputs_matches_eager_steps():
+    """One rank replays two graphs (discriminator chain; generators on the trainer's own stream): refilling the static
+    inputs between replays without any synchronisation must reproduce eager steps on the same sequence of batches,
+    generator outputs included."""
+    b, n = 32, 6
+    batches = [synthetic.mmgan_inputs(b, 50, seed=400 + i, device=DEV) for i in range(n)]
+    keys = ("piano_roll", "durations", "beats", "noise1", "noise2", "fake_a", "fake_b", "g1_in_a", "g1_in_b")
+    runs = []
+    for mode in ("eager", "graph"):
+        mm = _mm(17).to(DEV)
+        tr = MmganTrainer(mm, lr=0.01, compute_dtype="bf16")
+        outs = []
+        if mode == "graph":
+            st = {k: batches[0][k].clone() for k in keys}
+            tr.capture(*[st[k] for k in keys])                        # 2 warm-up iterations on batch 0
+            for i in range(2, n):
+                for k in keys:
+                    st[k].copy_(batches[i][k])
+                tr.replay()
+                outs.append((tr.last_g1.clone(), tr.last_g2.clone()))
+        else:
+            for i in (0, 0) + tuple(range(2, n)):
+                d = batches[i]
+                tr.step(*[d[k] for k in keys[:7]], g1_in_a=d["g1_in_a"], g1_in_b=d["g1_in_b"])
+                if i >= 2:
+                    outs.append((tr.last_g1.clone(), tr.last_g2.clone()))
+        torch.cuda.synchronize()
+        runs.append((outs, mm.discriminator.fc.weight.detach().clone(), tr.disc_loss_value(), tr.gen_loss_value()))
+    for (a1, a2), (b1, b2) in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    assert torch.equal(runs[0][1], runs[1][1]) and runs[0][2:] == runs[1][2:]
+
+
 def test_bf16_trainer_tracks_fp32_losses():
     b = 16
     losses = {}

@@ -310,6 +310,40 @@ def test_pipelined_graph_replay_matches_sequential_steps():
     assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
 
 
+def test_pipelined_replay_with_refilled_inputs_matches_eager_steps():
+    """The generator runs as a graph of its own on the trainer's stream: a caller that refills the static input buffers
+    between replays (what a data loader does) must get, per iteration, exactly what eager steps on the same inputs give
+    -- generated matrices included (they read ``noise`` on the other stream)."""
+    hw, b, n = (128, 216), 4, 6
+    batches = [synthetic.simnn_inputs(b, hw, seed=300 + i, device=DEV) for i in range(n)]
+    runs = []
+    for mode in ("seq", "graph"):
+        gen, disc = _build(9, True)
+        gen.to(DEV), disc.to(DEV)
+        tr = SimnnTrainer(gen, disc, compute_dtype="bf16")
+        gens = []
+        if mode == "graph":
+            real, fake, noise = (t.clone() for t in batches[0])
+            tr.capture(real, noise, fake, pipelined=True)            # 2 warm-up iterations on batch 0
+            for i in range(2, n):
+                for dst, src in zip((real, fake, noise), batches[i]):
+                    dst.copy_(src)                                     # no synchronisation: stream order must do
+                tr.replay()
+                gens.append(tr.last_generated.clone())
+            tr.flush()
+        else:
+            for i in (0, 0) + tuple(range(2, n)):
+                tr.step_pipelined(*[batches[i][k] for k in (0, 2, 1)])
+                if i >= 2:
+                    gens.append(tr.last_generated.clone())
+            tr.flush()
+        torch.cuda.synchronize()
+        runs.append((gens, disc.fc1.weight.detach().clone(), tr.disc_loss_value(), tr.gen_loss_value()))
+    for a, b_ in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(a, b_)
+    assert torch.equal(runs[0][1], runs[1][1]) and runs[0][2:] == runs[1][2:]
+
+
 def test_train_entry_point_runs_and_checkpoints(tmp_path):
     gen, disc, g_losses, d_losses = SIMNN.train(None, batch_size=4, max_steps=7, model_path=str(tmp_path), seed=0,
                                                 log=lambda *_: None)
