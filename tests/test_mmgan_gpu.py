@@ -192,11 +192,13 @@ def test_dcnn_vs_oracle(mode, tol_out, tol_grad, t):
         assert rel_l2(pg.grad, pr.grad) < tol_grad, (k, rel_l2(pg.grad, pr.grad))
 
 
-def test_fused_dcnn_kernel_vs_oracle_bf16():
-    """The one-kernel discriminator pass (forward + BCE + backward, everything in LDS) against the CPU oracle."""
+@pytest.mark.parametrize("t", [50, 48, 34, 32, 18, 16])
+def test_fused_dcnn_kernel_vs_oracle_bf16(t):
+    """The one-kernel discriminator pass (forward + BCE + backward, everything in LDS) against the CPU oracle, for every
+    roll length the kernel is instantiated for (the reference uses T = 50)."""
     from gan_des_midi_music_gen_amd import ops
-    t, b = 50, 6
-    assert ops.dcnn_fused_supported(t) and not ops.dcnn_fused_supported(256)
+    b = 6
+    assert ops.dcnn_fused_supported(t) and not ops.dcnn_fused_supported(256) and not ops.dcnn_fused_supported(20)
     torch.manual_seed(8)
     ref = om.DiscriminatorCNN(roll_size=(2, 128, t))
     d = synthetic.mmgan_inputs(b, t, seed=31)
@@ -215,6 +217,11 @@ def test_fused_dcnn_kernel_vs_oracle_bf16():
     for (k, pr), g in zip(ref.named_parameters(), grads):
         # bias gradients are sums of ~10^4 signed bf16-rounded terms with heavy cancellation: 1e-1; weights 5e-2
         tol = 1e-1 if k.endswith("bias") else 5e-2
+        if pr.numel() == 1:
+            # fc.bias: ONE number, the sum of 2b terms (sigmoid(z) - y) / b of both signs that nearly cancel; a logit error
+            # of 2e-2 moves each term by <= 5e-3 / b, so the sum is held to an absolute bound instead
+            assert abs(g.item() - pr.grad.item()) < 5e-3, (k, g.item(), pr.grad.item())
+            continue
         assert rel_l2(g.reshape(pr.shape), pr.grad) < tol, (k, rel_l2(g.reshape(pr.shape), pr.grad))
     # determinism + forward-only variant + a batch that gives several samples to one workgroup
     logits2, grads2 = ops.dcnn_fused(d["fake_a"].to(DEV), (d["piano_roll"].to(DEV), d["durations"].to(DEV)), t, 0.0,
