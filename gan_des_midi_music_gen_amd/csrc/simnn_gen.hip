@@ -43,10 +43,14 @@ __global__ __launch_bounds__(256) void gen_pack_kernel(const float* __restrict__
 }
 
 // ---- first layer: ConvT(noise_dim -> 128, k4, s1, p0) on a 1x1 input = a (B, noise_dim) x (noise_dim, 16*128) product,
-// with its BatchNorm statistics: a 512-thread workgroup owns 16 channels at all 16 positions for the WHOLE batch
+// with its BatchNorm statistics: a 256-thread workgroup owns L1_CH = 4 channels at all 16 positions for the WHOLE batch
 // (B <= 256), so the channel statistics are exact two-pass sums inside the workgroup and no partial / finalize launch
-// follows.  M = n (weights, A), N = b (noise, B operand), K = noise_dim padded to 128.
-__global__ __launch_bounds__(512) void gen_l1_kernel(const float* __restrict__ noise, int B, int noise_dim,
+// follows; 32 workgroups (with 16 channels per workgroup the 8 of them took 22 us: each wrote 256 KB and held 32
+// accumulator tiles per wave).  M = n (weights, A), N = b (noise, B operand), K = noise_dim padded to 128.
+// A tile of wave wv: rows 4 * pos_local + co (positions 4wv .. 4wv+3, the 4 channels): in the result lane (lr, lg) holds
+// the 4 channels of position 4wv + lg for sample lr of a batch tile -- one 16-byte store.
+constexpr int L1_CH = 4;
+__global__ __launch_bounds__(256) void gen_l1_kernel(const float* __restrict__ noise, int B, int noise_dim,
                                                      const __bf16* __restrict__ w1p, float* __restrict__ y1,
                                                      float momentum, float eps, float* __restrict__ running_mean,
                                                      float* __restrict__ running_var, int64_t* __restrict__ nbt,
@@ -54,101 +58,91 @@ __global__ __launch_bounds__(512) void gen_l1_kernel(const float* __restrict__ n
   constexpr int SK = L1_K + 8;                                             // padded LDS row (see convt_s2_bn_kernel)
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   __bf16* x_s = (__bf16*)dyn_smem;                                         // [256 b][SK]
-  __bf16* w_s = x_s + 256 * SK;                                            // [16 pos][16 co][SK]
-  __shared__ float red[8][16], cmean[16];
+  __bf16* w_s = x_s + 256 * SK;                                            // [16 pos][4 co][SK]
+  __shared__ float red[4][L1_CH], cmean[L1_CH];
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
-  const int c0 = blockIdx.x * 16;
-  // stage: weights of this channel block (256 rows x 128 k, 16-byte chunks), noise rows converted to bf16 (zero padded)
+  const int c0 = blockIdx.x * L1_CH;
+  // stage: weights of this channel block (64 rows x 128 k, 16-byte chunks), noise rows converted to bf16 (zero padded);
+  // all global loads are issued before the first conversion
   {
-    f32x4 wr[8];
+    f32x4 wr[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int i = t + 512 * k, row = i / (L1_K / 8), c8 = i % (L1_K / 8), pos = row >> 4, co = row & 15;
+    for (int k = 0; k < 4; ++k) {
+      const int i = t + 256 * k, row = i / (L1_K / 8), c8 = i % (L1_K / 8), pos = row >> 2, co = row & 3;
       wr[k] = *(const f32x4*)&w1p[((size_t)(pos * 128 + c0 + co)) * L1_K + 8 * c8];
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int i = t + 512 * k, row = i / (L1_K / 8), c8 = i % (L1_K / 8);
-      *(f32x4*)&w_s[row * SK + 8 * c8] = wr[k];
-    }
-  }
-  {   // noise: 4 values per thread and step, all 16 steps' loads in flight before the first conversion
     const bool vec = (noise_dim % 4 == 0) && (((uintptr_t)noise & 15) == 0);
-    f32x4 xr[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int i = t + 512 * k, b = i / (L1_K / 4), k4 = 4 * (i % (L1_K / 4));
-      xr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (b < B && k4 < noise_dim) {
-        const float* src = noise + (size_t)b * noise_dim + k4;
-        if (vec) xr[k] = *(const f32x4*)src;
-        else
+    for (int half = 0; half < 2; ++half) {
+      f32x4 xr[16];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) xr[k][e] = (k4 + e < noise_dim) ? src[e] : 0.f;
+      for (int k = 0; k < 16; ++k) {
+        const int i = t + 256 * (k + 16 * half), b = i / (L1_K / 4), k4 = 4 * (i % (L1_K / 4));
+        xr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (b < B && k4 < noise_dim) {
+          const float* src = noise + (size_t)b * noise_dim + k4;
+          if (vec) xr[k] = *(const f32x4*)src;
+          else
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xr[k][e] = (k4 + e < noise_dim) ? src[e] : 0.f;
+        }
       }
-    }
+      if (half == 0) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int i = t + 512 * k, b = i / (L1_K / 4), k4 = 4 * (i % (L1_K / 4));
-      bf16x4 h;
+        for (int k = 0; k < 4; ++k) {
+          const int i = t + 256 * k, row = i / (L1_K / 8), c8 = i % (L1_K / 8);
+          *(f32x4*)&w_s[row * SK + 8 * c8] = wr[k];
+        }
+      }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) h[e] = (__bf16)xr[k][e];
-      *(bf16x4*)&x_s[b * SK + k4] = h;
+      for (int k = 0; k < 16; ++k) {
+        const int i = t + 256 * (k + 16 * half), b = i / (L1_K / 4), k4 = 4 * (i % (L1_K / 4));
+        bf16x4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = (__bf16)xr[k][e];
+        *(bf16x4*)&x_s[b * SK + k4] = h;
+      }
     }
   }
   __syncthreads();
-  f32x4 acc[2][16];                                                        // [pos tile of this wave][batch tile]
+  f32x4 acc[16];                                                           // [batch tile]
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
-#pragma unroll
-    for (int bt = 0; bt < 16; ++bt) acc[p][bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int bt = 0; bt < 16; ++bt) acc[bt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < L1_K / 32; ++ks) {
-    bf16x8 af[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) af[p] = *(const bf16x8*)&w_s[((2 * wv + p) * 16 + lr) * SK + ks * 32 + 8 * lg];
+    const bf16x8 af = *(const bf16x8*)&w_s[(16 * wv + lr) * SK + ks * 32 + 8 * lg];
 #pragma unroll
     for (int bt = 0; bt < 16; ++bt) {
       const bf16x8 bf = *(const bf16x8*)&x_s[(bt * 16 + lr) * SK + ks * 32 + 8 * lg];
-#pragma unroll
-      for (int p = 0; p < 2; ++p) acc[p][bt] = mfma16(af[p], bf, acc[p][bt]);
+      acc[bt] = mfma16(af, bf, acc[bt]);
     }
   }
-  // C: col (lr) = b within the batch tile, rows 4*lg + r = channel c0 + 4*lg + r, at position 2*wv + p
+  // C: col (lr) = b within the batch tile, rows 4*lg + r = (position 4wv + lg, channel c0 + r)
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+  for (int bt = 0; bt < 16; ++bt) {
+    const int b = bt * 16 + lr;
+    if (b < B) *(f32x4*)&y1[((size_t)b * 16 + 4 * wv + lg) * 128 + c0] = acc[bt];
+  }
+  auto reduce = [&](auto value) {                                          // channel r: over tiles, the 64 lanes -> red[wv][r]
 #pragma unroll
-    for (int bt = 0; bt < 16; ++bt) {
-      const int b = bt * 16 + lr;
-      if (b < B) *(f32x4*)&y1[((size_t)b * 16 + 2 * wv + p) * 128 + c0 + 4 * lg] = acc[p][bt];
-    }
-  auto reduce = [&](auto value) {                                          // per channel r of this lane's group -> red[wv][4lg+r]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < L1_CH; ++r) {
       float sum = 0.f;
 #pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int bt = 0; bt < 16; ++bt) sum += (bt * 16 + lr < B) ? value(acc[p][bt][r], 4 * lg + r) : 0.f;
-      sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
-      sum += __shfl_xor(sum, 4, 64); sum += __shfl_xor(sum, 8, 64);
-      if (lr == 0) red[wv][4 * lg + r] = sum;
+      for (int bt = 0; bt < 16; ++bt) sum += (bt * 16 + lr < B) ? value(acc[bt][r], r) : 0.f;
+      sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+      sum += __shfl_xor(sum, 8, 64); sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+      if (l == 0) red[wv][r] = sum;
     }
   };
   const float n = (float)B * 16.f;
   reduce([&](float v, int) { return v; });
   __syncthreads();
-  if (t < 16) {
-    float sum = 0.f;
-    for (int w = 0; w < 8; ++w) sum += red[w][t];
-    cmean[t] = sum / n;
-  }
+  if (t < L1_CH) cmean[t] = (((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]) / n;
   __syncthreads();
   reduce([&](float v, int c) { const float d = v - cmean[c]; return d * d; });
   __syncthreads();
-  if (t < 16) {
-    float m2 = 0.f;
-    for (int w = 0; w < 8; ++w) m2 += red[w][t];
+  if (t < L1_CH) {
+    const float m2 = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
     const int c = c0 + t;
     save_mean[c] = cmean[t];
     save_invstd[c] = 1.0f / sqrtf(m2 / n + eps);
@@ -383,9 +377,9 @@ extern "C" int gdm_simnn_gen_first(const float* noise, int B, int noise_dim, con
   GDM_REQUIRE(noise && pack && y1 && save_mean && save_invstd, "gdm_simnn_gen_first: null pointer");
   GDM_REQUIRE(B > 1 && B <= 256 && noise_dim >= 1 && noise_dim <= L1_K && ((uintptr_t)y1 & 15) == 0,
               "gdm_simnn_gen_first: batch %d outside 2..256 (the workgroup owns the whole batch) or noise_dim > %d", B, L1_K);
-  const size_t sm = (size_t)2 * 256 * (L1_K + 8) * 2;
+  const size_t sm = (size_t)(256 + 16 * L1_CH) * (L1_K + 8) * 2;
   allow_dyn_lds(gen_l1_kernel, sm);
-  hipLaunchKernelGGL(gen_l1_kernel, dim3(8), dim3(512), sm, (hipStream_t)stream, noise, B, noise_dim,
+  hipLaunchKernelGGL(gen_l1_kernel, dim3(128 / L1_CH), dim3(256), sm, (hipStream_t)stream, noise, B, noise_dim,
                      (const __bf16*)pack + GP_W2 + GP_W3, y1, momentum, eps, running_mean, running_var,
                      num_batches_tracked, save_mean, save_invstd);
   GDM_LAUNCH_OK("gdm_simnn_gen_first");
