@@ -19,6 +19,9 @@ python bench.py --no-cpu-baseline --no-roofline --no-pipeline > gpurun_out/bench
 python bench.py --no-cpu-baseline --dtype fp32 > gpurun_out/bench_simnn_fp32.json 2>> gpurun_out/bench_default.err
 python bench.py --no-cpu-baseline --no-roofline --workload mmgan --no-graph --steps 200 --warmup 20 > gpurun_out/bench_mmgan_eager.json 2>> gpurun_out/bench_default.err
 python bench.py --no-cpu-baseline --no-roofline --workload mmgan --batch 16 > gpurun_out/bench_mmgan_b16.json 2>> gpurun_out/bench_default.err
+python bench.py --batch 16 --width 64 --no-cpu-baseline --no-roofline > gpurun_out/bench_simnn_c1_b16_w64.json 2>> gpurun_out/bench_default.err
+python bench.py --batch 16 --width 216 --no-cpu-baseline --no-roofline > gpurun_out/bench_simnn_c1_b16_w216.json 2>> gpurun_out/bench_default.err
+python bench.py --batch 128 --width 216 --no-cpu-baseline --no-roofline > gpurun_out/bench_simnn_c5_b128_w216.json 2>> gpurun_out/bench_default.err
 rm -rf gpurun_out/tl_mmgan
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl_mmgan -- python bench.py --workload mmgan --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/tl_mmgan.log 2>&1
 python tools/graph_timeline.py gpurun_out/tl_mmgan > gpurun_out/mmgan_replay_timeline.txt

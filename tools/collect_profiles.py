@@ -31,7 +31,7 @@ copy(os.path.join(out, "bench_default.json"), f"{tag}_bench_default.json")
 copy(os.path.join(out, "bench_mmgan.json"), f"{tag}_bench_mmgan.json")
 copy(os.path.join(out, "pmc_ops_summary.txt"), f"{tag}_conv_kernels_b512_pmc_sq.txt")
 for name in ("bench_simnn_eager", "bench_simnn_elided", "bench_simnn_nopipeline", "bench_simnn_fp32", "bench_mmgan_eager",
-             "bench_mmgan_b16"):
+             "bench_mmgan_b16", "bench_simnn_c1_b16_w64", "bench_simnn_c1_b16_w216", "bench_simnn_c5_b128_w216"):
     copy(os.path.join(out, name + ".json"), f"{tag}_{name}.json")
 copy(os.path.join(out, "pytest_gpu_r02.log"), f"{tag}_pytest_gpu.log")
 copy(os.path.join(out, "parity_r02.jsonl"), f"{tag}_parity_measurements.jsonl")
