@@ -1484,7 +1484,7 @@ extern "C" int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* 
               "gdm_simnn_conv1_fwd: batch of %d %dx%d inputs exceeds 2 GiB per tensor", B, H, W);
   const int64_t n_rows = (int64_t)B * H1;                                // a wave walks whole pooled rows
   int64_t blocks = (n_rows + 3) / 4;                                     // 4 waves per workgroup
-  static const int cap1 = tuned_cap("GDM_C1_CAP", 2048);               // persistent: 8 workgroups per CU
+  static const int cap1 = tuned_cap("GDM_C1_CAP", 1536);               // persistent: 6 workgroups per CU (2048: +0.6 % per iteration)
   if (blocks > cap1) blocks = cap1;
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                                        x, w, bias, B, H, W, H1, W1, (int)n_rows, (T*)p1, code1));
