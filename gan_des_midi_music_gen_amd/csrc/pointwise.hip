@@ -653,8 +653,8 @@ constexpr int HEAD_ROWS = 8;    // batch rows per workgroup (a launch is latency
 // partial layout per workgroup: [0,128) dw2, [128,256) db1, [256] db2, [257] loss
 __global__ __launch_bounds__(256) void simnn_head_kernel(const float* __restrict__ h1, const float* __restrict__ w2,
                                                          const float* __restrict__ b2, int n, int n0, float y0,
-                                                         float y1, float* __restrict__ prob, float* __restrict__ dh1,
-                                                         float* __restrict__ partials) {
+                                                         float y1, float* __restrict__ prob, void* __restrict__ dh1,
+                                                         int dh1_bf16, float* __restrict__ partials) {
   __shared__ float dz_s[HEAD_ROWS], lt_s[HEAD_ROWS], part[2][256];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int r0 = blockIdx.x * HEAD_ROWS, r1 = min(n, r0 + HEAD_ROWS);
@@ -710,7 +710,10 @@ __global__ __launch_bounds__(256) void simnn_head_kernel(const float* __restrict
     const int b = r0 + grp + 2 * k;
     const float d = dz_s[grp + 2 * k];
     const float g = hh[k] > 0.f ? d * wj : 0.f;
-    if (dh1 != nullptr && b < r1) dh1[(int64_t)b * 128 + j] = g;
+    if (dh1 != nullptr && b < r1) {
+      if (dh1_bf16) ((__bf16*)dh1)[(int64_t)b * 128 + j] = (__bf16)g;      // the two fc1 GEMMs' operand in bf16 mode
+      else ((float*)dh1)[(int64_t)b * 128 + j] = g;
+    }
     s_w = fmaf(d, hh[k], s_w);
     s_b1 += g;
   }
@@ -753,11 +756,12 @@ extern "C" size_t gdm_simnn_head_workspace_bytes(int n) {
 }
 
 extern "C" int gdm_simnn_head(const float* h1, const float* w2, const float* b2, int n, int n0, float y0, float y1,
-                              float* prob, float* loss, int accumulate_loss, float* dh1, float* dw2, float* db2,
-                              float* db1, void* workspace, size_t workspace_bytes, void* stream) {
+                              float* prob, float* loss, int accumulate_loss, void* dh1, int dh1_dtype, float* dw2,
+                              float* db2, float* db1, void* workspace, size_t workspace_bytes, void* stream) {
   GDM_REQUIRE(h1 && w2 && b2 && prob && loss, "gdm_simnn_head: null pointer");
   GDM_REQUIRE(n > 0 && n <= 65536 && n0 > 0 && n0 <= n, "gdm_simnn_head: bad batch n=%d n0=%d", n, n0);
   GDM_REQUIRE(dh1 == nullptr || (dw2 && db2 && db1), "gdm_simnn_head: gradient outputs missing");
+  GDM_REQUIRE(gdm_dtype_ok(dh1_dtype), "gdm_simnn_head: bad dh1 dtype");
   if (!workspace || workspace_bytes < gdm_simnn_head_workspace_bytes(n)) {
     gdm_set_error("gdm_simnn_head: workspace too small");
     return GDM_EWORKSPACE;
@@ -765,7 +769,7 @@ extern "C" int gdm_simnn_head(const float* h1, const float* w2, const float* b2,
   const int groups = (n + HEAD_ROWS - 1) / HEAD_ROWS;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(simnn_head_kernel, dim3(groups), dim3(256), 0, s, h1, w2, b2, n, n0, y0, y1, prob, dh1,
-                     (float*)workspace);
+                     dh1_dtype == GDM_BF16 ? 1 : 0, (float*)workspace);
   hipLaunchKernelGGL(simnn_head_final, dim3(1), dim3(320), 0, s, (const float*)workspace, groups, loss,
                      accumulate_loss, dh1 ? dw2 : nullptr, db2, db1);
   GDM_LAUNCH_OK("gdm_simnn_head");

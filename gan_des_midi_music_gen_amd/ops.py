@@ -460,10 +460,11 @@ def simnn_conv1_bwd_data(dp1, code1, w, h, wd):
     return dx
 
 
-def simnn_head(h1, w2, b2, n0, y0, y1, *, loss_out, accumulate_loss=False, want_grad=True, grad_out=None):
+def simnn_head(h1, w2, b2, n0, y0, y1, *, loss_out, accumulate_loss=False, want_grad=True, grad_out=None, dh_dtype=F32):
     """Fused fc2 + sigmoid + BCE(+backward) of model 1's discriminator head.
 
     h1 (n,128) fp32; rows [0,n0) carry label y0, the rest y1.  grad_out = (dw2, db2, db1) views to fill.
+    dh_dtype: dtype of the returned dh1 (BF16 in bf16 mode: it is only ever the operand of fc1's two backward GEMMs).
     Returns (prob (n,), dh1 (n,128) or None, (dw2, db2, db1) or None)."""
     _need_gpu(h1, w2, b2, loss_out)
     assert h1.dim() == 2 and h1.shape[1] == 128 and h1.is_contiguous() and h1.dtype == torch.float32
@@ -471,7 +472,7 @@ def simnn_head(h1, w2, b2, n0, y0, y1, *, loss_out, accumulate_loss=False, want_
     prob = torch.empty(n, dtype=torch.float32, device=h1.device)
     dh1 = dw2 = db2 = db1 = None
     if want_grad:
-        dh1 = torch.empty_like(h1)
+        dh1 = torch.empty(h1.shape, dtype=_TORCH_DT[dh_dtype], device=h1.device)
         if grad_out is not None:
             dw2, db2, db1 = grad_out
             assert dw2.numel() == 128 and db2.numel() == 1 and db1.numel() == 128
@@ -482,7 +483,7 @@ def simnn_head(h1, w2, b2, n0, y0, y1, *, loss_out, accumulate_loss=False, want_
     nb = _lib.load().gdm_simnn_head_workspace_bytes(n)
     ws = workspace(nb, h1.device)
     _call("gdm_simnn_head", _p(h1), _p(w2), _p(b2), n, n0, float(y0), float(y1), _p(prob), _p(loss_out),
-          1 if accumulate_loss else 0, _p(dh1), _p(dw2), _p(db2), _p(db1), _p(ws), nb, _stream())
+          1 if accumulate_loss else 0, _p(dh1), int(dh_dtype), _p(dw2), _p(db2), _p(db1), _p(ws), nb, _stream())
     return prob, dh1, ((dw2, db2, db1) if want_grad else None)
 
 

@@ -374,7 +374,8 @@ class SimnnTrainer(_TrainerBase):
         ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
         hid, saved = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1, code1))
         # fc2 + sigmoid + both BCE terms (labels 0.9 / 0.1, SIMNN.py:284-311) + head backward: one launch pair
-        _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 0.9, 0.1, loss_out=self.loss_d, grad_out=(gv[6], gv[7], gv[5]))
+        _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 0.9, 0.1, loss_out=self.loss_d, grad_out=(gv[6], gv[7], gv[5]),
+                                      dh_dtype=dt)
         self._d_backward(saved, dh, pack, wf1p, gv, (real, fake), keep)
         # Adam also rewrites the weight-derived operands in place (fc1's operand copy inside the kernel, conv2's packed
         # images right after): they are cross-iteration state, so their storage must be stable under graph replay
@@ -384,7 +385,8 @@ class SimnnTrainer(_TrainerBase):
         code1g = torch.empty((b, h1, w1s), dtype=torch.int64, device=real.device)
         ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1g, code1g))
         hid_g, saved_g = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1g, code1g))
-        _prob, dh_g, _ = ops.simnn_head(hid_g, wf2, bf2, b, 1.0, 1.0, loss_out=self.loss_g, want_grad=not self.elide)
+        _prob, dh_g, _ = ops.simnn_head(hid_g, wf2, bf2, b, 1.0, 1.0, loss_out=self.loss_g, want_grad=not self.elide,
+                                        dh_dtype=dt)
         if not self.elide:
             # dead values: gen_loss.backward() only fills D's .grad, which the next zero_grad() wipes (SIMNN.py:330,
             # 282); they are computed (faithful mode) into a scratch set of gradient buffers
@@ -407,7 +409,8 @@ class SimnnTrainer(_TrainerBase):
         pack, wf1p = self._prepared
         b = fake.shape[0]
         hid_g, saved_g = Fn.simnn_disc_features(fake, w1, b1, pack, b2, wf1p, bf1, dt)
-        _prob, dh_g, _ = ops.simnn_head(hid_g, wf2, bf2, b, 1.0, 1.0, loss_out=self.loss_g, want_grad=not self.elide)
+        _prob, dh_g, _ = ops.simnn_head(hid_g, wf2, bf2, b, 1.0, 1.0, loss_out=self.loss_g, want_grad=not self.elide,
+                                        dh_dtype=dt)
         if not self.elide:
             if self._scratch_grads is None:
                 self._scratch_grads = [torch.empty_like(g) for g in self.d.grad_views]
@@ -468,7 +471,8 @@ class SimnnTrainer(_TrainerBase):
                 self._fake_buf = torch.empty_like(fake)
             self._fake_buf.copy_(fake)
         hid, saved = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1, code1))
-        _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 0.9, 0.1, loss_out=self.loss_d, grad_out=(gv[6], gv[7], gv[5]))
+        _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 0.9, 0.1, loss_out=self.loss_d, grad_out=(gv[6], gv[7], gv[5]),
+                                      dh_dtype=dt)
         self._d_backward(saved, dh, pack, wf1p, gv, (real, fake), keep)
         if side:
             main.wait_stream(side[2])

@@ -196,8 +196,8 @@ int gdm_simnn_conv1_bwd_data(const void* dp1, const uint64_t* code1, const float
  * summed in order by a second launch.  workspace >= gdm_simnn_head_workspace_bytes(n).                              */
 size_t gdm_simnn_head_workspace_bytes(int n);
 int gdm_simnn_head(const float* h1, const float* w2, const float* b2, int n, int n0, float y0, float y1, float* prob,
-                   float* loss, int accumulate_loss, float* dh1, float* dw2, float* db2, float* db1, void* workspace,
-                   size_t workspace_bytes, void* stream);
+                   float* loss, int accumulate_loss, void* dh1, int dh1_dtype /* GDM_F32 | GDM_BF16: the fc1 GEMMs' operand */,
+                   float* dw2, float* db2, float* db1, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- model 2 -----------------------------------------------------------------------------------------------------
  * One generator block in one launch: out = act(BatchNorm1d(x W^T + b)) for up to gdm_linear_bn_act_max_rows() rows
