@@ -53,3 +53,10 @@ if os.path.exists(src):
                         "kernel: conv2_bwd_data_kernel<FUSE>"}
         json.dump(t, open(os.path.join(prof, "traffic.json"), "w"), indent=1)
         print("profiles/traffic.json:", t["simnn_bf16"])
+
+# per-kernel time / measured-traffic table of the model-1 iteration
+import subprocess
+md = os.path.join(prof, f"{tag}_kernel_roofline.md")
+with open(md, "w") as f:
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_roofline.py"), tag], stdout=f, check=False)
+print(f"profiles/{tag}_kernel_roofline.md")
