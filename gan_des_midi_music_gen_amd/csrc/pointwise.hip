@@ -115,7 +115,12 @@ __global__ __launch_bounds__(256) void adam_dev_pc_kernel(float* __restrict__ p,
     const int64_t k = base + (int64_t)c * P + pp;
     f32x4 gg = *(const f32x4*)&tile[cl][4 * tx], pv, mv, vv;
     if (full) {
+#ifndef GDM_ADAM_DEFAULT_POLICY       /* p, m, v are read once and written once per step: non-temporal */
+      pv = __builtin_nontemporal_load((const f32x4*)(p + k)); mv = __builtin_nontemporal_load((const f32x4*)(m + k));
+      vv = __builtin_nontemporal_load((const f32x4*)(v + k));
+#else
       pv = *(const f32x4*)(p + k); mv = *(const f32x4*)(m + k); vv = *(const f32x4*)(v + k);
+#endif
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -134,7 +139,12 @@ __global__ __launch_bounds__(256) void adam_dev_pc_kernel(float* __restrict__ p,
       vv[e] = vj;
     }
     if (full) {
+#ifndef GDM_ADAM_DEFAULT_POLICY       /* p, m, v are read once and written once per step: non-temporal */
+      __builtin_nontemporal_store(pv, (f32x4*)(p + k)); __builtin_nontemporal_store(mv, (f32x4*)(m + k));
+      __builtin_nontemporal_store(vv, (f32x4*)(v + k));
+#else
       *(f32x4*)(p + k) = pv; *(f32x4*)(m + k) = mv; *(f32x4*)(v + k) = vv;
+#endif
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)

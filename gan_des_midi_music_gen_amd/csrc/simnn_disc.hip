@@ -86,17 +86,30 @@ __device__ __forceinline__ uint64_t buf_load8(rsrc_t r, uint32_t off) {
 __device__ __forceinline__ float buf_load4(rsrc_t r, uint32_t off) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
+// Cache policy of the big write-once activation streams (conv1: p1 + code1, conv2: p2 + code2; 84 + 75 MB per 256 samples):
+// non-temporal.  They are consumed by a LATER kernel, and on this 8-XCD part a kernel boundary writes the XCD's dirty L2
+// lines back before the dependent kernel starts; streaming them out as they are produced took 0.5-0.9 % off the
+// iteration in same-box A/B (the kernels themselves run as before).  -DGDM_ACT_STORE_AUX=0 restores the default policy.
+#ifndef GDM_ACT_STORE_AUX
+#define GDM_ACT_STORE_AUX 2
+#endif
+#ifndef GDM_ACT_STORE_AUX2
+#define GDM_ACT_STORE_AUX2 GDM_ACT_STORE_AUX
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store16(rsrc_t r, uint32_t off, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store8(rsrc_t r, uint32_t off, uint64_t v) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0, AUX);
 }
 __device__ __forceinline__ void buf_store4(rsrc_t r, uint32_t off, uint32_t v) {
   __builtin_amdgcn_raw_buffer_store_b32(v, r, off, 0, 0);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void buf_store2(rsrc_t r, uint32_t off, uint32_t v) {
-  __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, off, 0, AUX);
 }
 
 // =====================================================================================================================
@@ -199,11 +212,11 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       bf16x4 h;
 #pragma unroll
       for (int r = 0; r < 4; ++r) h[r] = (__bf16)best[r];
-      buf_store8(pr, ok ? pix * 32u + 8u * lg : BUF_OOB, __builtin_bit_cast(uint64_t, h));
+      buf_store8<GDM_ACT_STORE_AUX>(pr, ok ? pix * 32u + 8u * lg : BUF_OOB, __builtin_bit_cast(uint64_t, h));
     } else {
       buf_store16(pr, ok ? pix * 64u + 16u * lg : BUF_OOB, (f32x4){best[0], best[1], best[2], best[3]});
     }
-    buf_store2(cr, ok ? pix * 8u + 2u * lg : BUF_OOB, field);
+    buf_store2<GDM_ACT_STORE_AUX2>(cr, ok ? pix * 8u + 2u * lg : BUF_OOB, field);
   };
   if (wave >= n_rows) return;
   // DEPTH units in flight per wave; every trip issues the same loads and stores (units past the end re-read valid
@@ -604,12 +617,12 @@ __device__ __forceinline__ void conv2_fwd_tile(const T* __restrict__ in_s, const
     bf16x8 h;
 #pragma unroll
     for (int e = 0; e < 8; ++e) h[e] = (__bf16)best[e];
-    buf_store16(p2r, ok ? gi * 2u : BUF_OOB, __builtin_bit_cast(f32x4, h));
+    buf_store16<GDM_ACT_STORE_AUX>(p2r, ok ? gi * 2u : BUF_OOB, __builtin_bit_cast(f32x4, h));
   } else {
     buf_store16(p2r, ok ? gi * 4u : BUF_OOB, (f32x4){best[0], best[1], best[2], best[3]});
     buf_store16(p2r, ok ? gi * 4u + 16u : BUF_OOB, (f32x4){best[4], best[5], best[6], best[7]});
   }
-  buf_store8(code2r, ok ? gi : BUF_OOB, codes);
+  buf_store8<GDM_ACT_STORE_AUX>(code2r, ok ? gi : BUF_OOB, codes);
 }
 
 // Persistent over tiles; the weight image and the biases are fetched once per workgroup; input bands are prefetched
