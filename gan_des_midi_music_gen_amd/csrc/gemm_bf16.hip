@@ -252,7 +252,13 @@ __global__ __launch_bounds__(NT) void gemm_bf16_fast(GemmArgs g) {
           const int n = n0 + wn * 64 + 16 * j + 4 * lg;
           if (n >= g.N) continue;
           float* dst = g.ws + ((int64_t)zs * g.M + m) * g.N + n;
+#ifndef GDM_GEMM_DEFAULT_STORES
+          // (outputs and split-K slabs are consumed by a later kernel: non-temporal, like the activation streams of
+          //  simnn_disc.hip -- 0.7 % per iteration in same-box A/B)
+          if (vec_ok) __builtin_nontemporal_store(acc[i][j], (f32x4*)dst);
+#else
           if (vec_ok) *(f32x4*)dst = acc[i][j];
+#endif
           else
             for (int r = 0; r < 4 && n + r < g.N; ++r) dst[r] = acc[i][j][r];
         }
@@ -300,7 +306,11 @@ __global__ __launch_bounds__(NT) void gemm_bf16_fast(GemmArgs g) {
               hv[r] = (__bf16)act_const<ACT>(v0[r], g.slope);
               hv[4 + r] = (__bf16)act_const<ACT>(v1[r], g.slope);
             }
+#ifndef GDM_GEMM_DEFAULT_STORES
+            __builtin_nontemporal_store(hv, (bf16x8*)((__bf16*)g.C + (int64_t)m * g.scm + nn));
+#else
             *(bf16x8*)((__bf16*)g.C + (int64_t)m * g.scm + nn) = hv;
+#endif
           }
         } else {
 #pragma unroll
@@ -314,7 +324,11 @@ __global__ __launch_bounds__(NT) void gemm_bf16_fast(GemmArgs g) {
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = act_const<ACT>(v[r], g.slope);
+#ifndef GDM_GEMM_DEFAULT_STORES
+            __builtin_nontemporal_store(v, (f32x4*)((float*)g.C + (int64_t)m * g.scm + nn));
+#else
             *(f32x4*)((float*)g.C + (int64_t)m * g.scm + nn) = v;
+#endif
           }
         }
       }

@@ -77,14 +77,21 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, uint32_t bytes) {
 }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+#ifndef GDM_IN_LOAD_AUX
+#define GDM_IN_LOAD_AUX 0            // cache policy of the x / code1 loads: non-temporal (2) was measured 3 % SLOWER (x is
+                                     // read again by the backward of the same iteration: it wants to stay in the Infinity Cache)
+#endif
+template <int AUX = 0>
 __device__ __forceinline__ f32x4 buf_load16(rsrc_t r, uint32_t off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ uint64_t buf_load8(rsrc_t r, uint32_t off) {
-  return __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+  return __builtin_bit_cast(uint64_t, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ float buf_load4(rsrc_t r, uint32_t off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, AUX));
 }
 // Cache policy of the big write-once activation streams (conv1: p1 + code1, conv2: p2 + code2; 84 + 75 MB per 256 samples):
 // non-temporal.  They are consumed by a LATER kernel, and on this 8-XCD part a kernel boundary writes the XCD's dirty L2
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       // address unit charges for
 #pragma unroll
       for (int dy = 0; dy < 2; ++dy) {
-        const uint64_t two = buf_load8(xr, base + loff[2 * dy]);
+        const uint64_t two = buf_load8<GDM_IN_LOAD_AUX>(xr, base + loff[2 * dy]);
         xv[2 * dy] = __builtin_bit_cast(float, (uint32_t)two);
         xv[2 * dy + 1] = __builtin_bit_cast(float, (uint32_t)(two >> 32));
       }
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     const bool rok[2] = {(unsigned)row0 < (unsigned)H, (unsigned)(row0 + 1) < (unsigned)H};
     const bool cok[2] = {(unsigned)col0 < (unsigned)W, (unsigned)(col0 + 1) < (unsigned)W};
 #pragma unroll
-    for (int p = 0; p < 4; ++p) xv[p] = buf_load4(xr, (rok[p >> 1] && cok[p & 1]) ? base + loff[p] : BUF_OOB);
+    for (int p = 0; p < 4; ++p) xv[p] = buf_load4<GDM_IN_LOAD_AUX>(xr, (rok[p >> 1] && cok[p & 1]) ? base + loff[p] : BUF_OOB);
   };
   auto finish = [&](const Slot& q, const float (&xv)[4]) {
     f32x4 acc[4];
@@ -775,8 +782,8 @@ __device__ __forceinline__ void bd_issue(BdStepRegs<T, FUSE, XVEC>& rg, const Bd
       // XVEC: W % 4 == 0, a 4-column vector is inside or outside the image as a whole
       const bool ok = (unsigned)(xr0 + ln.x_br[k]) < (unsigned)H && (unsigned)(xc0 + ln.x_bc[k]) < (unsigned)W;
       const uint32_t off = ok ? xbase + ln.x_off[k] : BUF_OOB;
-      if constexpr (XVEC) rg.xv4[k] = buf_load16(xr_, off);
-      else rg.xv[k] = buf_load4(xr_, off);
+      if constexpr (XVEC) rg.xv4[k] = buf_load16<GDM_IN_LOAD_AUX>(xr_, off);
+      else rg.xv[k] = buf_load4<GDM_IN_LOAD_AUX>(xr_, off);
     }
     // conv1 codes of this wave's 16 columns, rows 4rq .. 4rq+3
     const int iw = c0 + 16 * wv + lr;
@@ -784,7 +791,7 @@ __device__ __forceinline__ void bd_issue(BdStepRegs<T, FUSE, XVEC>& rg, const Bd
 #pragma unroll
     for (int ir = 0; ir < 4; ++ir) {
       const bool ok = (unsigned)(ROWS * rq + ir) < (unsigned)H1 && iw < W1;
-      rg.codes[ir] = buf_load8(rs.code1, ok ? cbase + (uint32_t)(ir * W1) * 8u : BUF_OOB);
+      rg.codes[ir] = buf_load8<GDM_IN_LOAD_AUX>(rs.code1, ok ? cbase + (uint32_t)(ir * W1) * 8u : BUF_OOB);
     }
   }
 }
