@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--seq", type=int, default=50, help="piano-roll length T (mmgan)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short secondary measurements (model 2 at B=256 / B=16, model 1 in exact fp32)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="model 1: run the generator half of an iteration inside the same call (SimnnTrainer.step)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
@@ -195,12 +197,19 @@ def host_cores():
 
 
 def cpu_baseline(args):
-    """Oracle (CPU restatement of the reference loop) on the host cores; bounded sample, same geometry/mode."""
+    """Oracle (CPU restatement of the reference loop) on the host cores; bounded sample, same geometry/mode.
+
+    Returns (cpu_baseline object, parity record): the oracle starts from the benchmark's weights (seed 0) and inputs
+    (seed 1234), so the (disc_loss, gen_loss) pairs of its iterations -- the warm-up call is iteration 0 -- are what a
+    fresh GPU trainer on the same state must reproduce (``loss_parity``).  parity = {"init": state_dicts before the
+    first iteration, "losses": [(d, g), ...]}."""
+    import copy
     from oracle import simnn as osn, mmgan as om, steps as ost
     from gan_des_midi_music_gen_amd import synthetic
     cores = host_cores()
     torch.set_num_threads(cores)
     elide = args.mode == "elided"
+    losses = []
     if args.workload == "simnn":
         b, hw = args.batch, (128, args.width)      # the benchmarked batch (256: ~4 s per iteration on 16 threads)
         torch.manual_seed(0)
@@ -209,7 +218,8 @@ def cpu_baseline(args):
         g_opt = ost.Adam(gen.parameters(), lr=0.00002, betas=(0.5, 0.999))
         d_opt = ost.Adam(disc.parameters(), lr=0.00002, betas=(0.5, 0.999))
         real, fake, noise = synthetic.simnn_inputs(b, hw, seed=1234)
-        fn = lambda: ost.simnn_iteration(gen, disc, g_opt, d_opt, real, noise, fake, elide)  # noqa: E731
+        init = (copy.deepcopy(gen.state_dict()), copy.deepcopy(disc.state_dict()))
+        fn = lambda: losses.append(ost.simnn_iteration(gen, disc, g_opt, d_opt, real, noise, fake, elide)[:2])  # noqa: E731
         sample = f"oracle.simnn_iteration, batch {b}, 128x{args.width}, fp32, {args.mode}"
     else:
         b = args.batch
@@ -218,9 +228,10 @@ def cpu_baseline(args):
         g_opt = ost.Adam(list(mm.generator1.parameters()) + list(mm.generator2.parameters()), lr=0.01)
         d_opt = ost.Adam(mm.discriminator.parameters(), lr=0.01)
         d = synthetic.mmgan_inputs(b, args.seq, seed=1234)
-        fn = lambda: ost.mmgan_iteration(mm, g_opt, d_opt, d["piano_roll"], d["durations"], d["beats"],  # noqa: E731
-                                         d["noise1"], d["noise2"], d["g1_in_a"], d["g1_in_b"], d["fake_a"],
-                                         d["fake_b"], 1, elide)
+        init = (copy.deepcopy(mm.state_dict()),)
+        fn = lambda: losses.append(ost.mmgan_iteration(mm, g_opt, d_opt, d["piano_roll"], d["durations"],  # noqa: E731
+                                                       d["beats"], d["noise1"], d["noise2"], d["g1_in_a"], d["g1_in_b"],
+                                                       d["fake_a"], d["fake_b"], 1, elide)[:2])
         sample = f"oracle.mmgan_iteration, batch {b}, T={args.seq}, fp32, {args.mode}"
     fn()                                           # warm-up (allocator, thread pool)
     t0 = time.perf_counter()
@@ -231,56 +242,100 @@ def cpu_baseline(args):
         el = time.perf_counter() - t0
         if (el > 12.0 and n >= 3) or n >= 200 or el > 40.0:      # >= 3 iterations, ~12-20 s of CPU work
             break
-    return {"value": round(b * n / el, 2), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{sample}; {n} iterations in {el:.1f} s"}
+    return ({"value": round(b * n / el, 2), "unit": "samples/s", "cores": cores, "kind": "port",
+             "sample": f"{sample}; {n} iterations in {el:.1f} s"}, {"init": init, "losses": losses})
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus))        # before anything touches the GPU in this process
-    if os.environ.get("GDM_BENCH_RENDEZVOUS_ONLY") == "1":
-        return rendezvous_only(args)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
-    rank, world, local = setup_dist(args.gpus)
-    dev = torch.device("cuda", local)
-    import torch.distributed as dist
-    from gan_des_midi_music_gen_amd import _lib, ops
-    if _lib.load().gdm_build_flavor() != 0 and os.environ.get("GDM_BENCH_ALLOW_EXPERIMENT") != "1":   # (A/B runs of variant libraries)
-        raise SystemExit("libgdm_hip.so was built with experiment switches (GDM_HIPCC_FLAGS): rebuild with the shipped "
-                         "flags (`python -m gan_des_midi_music_gen_amd.build`) before benchmarking")
+def loss_parity(args, parity, dev):
+    """The metric's "D-loss parity vs CPU": a FRESH trainer (the oracle's initial weights, the benchmark inputs, the
+    benchmarked arithmetic) runs as many iterations as the oracle did for ``cpu_baseline`` and its (disc_loss, gen_loss)
+    pairs are compared with the oracle's (GAN_DES/SIMNN.py:289-334 / network_tests.py:304-321 restated in
+    oracle/steps.py).  Model 1 runs free (tolerance = the parity tests' 50-iteration bound); model 2's bf16 trajectory is
+    only comparable from identical state, so only its first iteration is held to the bound."""
+    from gan_des_midi_music_gen_amd import SIMNN, network_tests as NT, synthetic
+    from gan_des_midi_music_gen_amd.train import MmganTrainer, SimnnTrainer
+    want = parity["losses"]
+    elide = args.mode == "elided"
+    got = []
+    if args.workload == "simnn":
+        hw = (128, args.width)
+        gen, disc = SIMNN.Generator(), SIMNN.Discriminator(input_hw=hw)
+        gen.load_state_dict(parity["init"][0])
+        disc.load_state_dict(parity["init"][1])
+        tr = SimnnTrainer(gen.to(dev), disc.to(dev), compute_dtype=args.dtype, elide_dead_backward=elide)
+        real, fake, noise = synthetic.simnn_inputs(args.batch, hw, seed=1234, device=dev)
+        for _ in want:
+            tr.step(real, noise, fake)
+            got.append((tr.disc_loss_value(), tr.gen_loss_value()))
+        k = len(want)
+        tol = 2e-3 if args.dtype == "bf16" else 1e-4
+        rel = False
+    else:
+        mm = NT.MultiModalGAN(z_dim=50, adj_size=(64, 64), roll_size=(2, 128, args.seq), input_dim=50, output_dim=20,
+                              instrument=0, start=100, end=100 + args.seq, device=dev)
+        mm.load_state_dict(parity["init"][0])
+        mm.to(dev).train()
+        tr = MmganTrainer(mm, compute_dtype=args.dtype, elide_dead_backward=elide)
+        d = synthetic.mmgan_inputs(args.batch, args.seq, seed=1234, device=dev)
+        tr.step(d["piano_roll"], d["durations"], d["beats"], d["noise1"], d["noise2"], d["fake_a"], d["fake_b"],
+                g1_in_a=d["g1_in_a"], g1_in_b=d["g1_in_b"])
+        got.append((tr.disc_loss_value(), tr.gen_loss_value()))
+        k = 1
+        tol = 2e-2 if args.dtype == "bf16" else 2e-3
+        rel = True
+    dd = [abs(g[0] - w[0]) / (max(1.0, abs(w[0])) if rel else 1.0) for g, w in zip(got[:k], want[:k])]
+    dg = [abs(g[1] - w[1]) / (max(1.0, abs(w[1])) if rel else 1.0) for g, w in zip(got[:k], want[:k])]
+    ok = all(x == x and x <= tol for x in dd + dg)
+    del tr
+    return {"iters": k, "max_abs_d": float(f"{max(dd):.3e}"), "max_abs_g": float(f"{max(dg):.3e}"), "tol": tol,
+            "relative_to_max_1_abs_loss": rel, "pass": bool(ok),
+            "gpu": [[round(a, 6), round(b, 6)] for a, b in got[:k]],
+            "cpu": [[round(a, 6), round(b, 6)] for a, b in want[:k]],
+            "what": "fresh trainer vs oracle/steps.py from the same weights (seed 0) and inputs (seed 1234), "
+                    + ("free-running" if not rel else "first iteration (model 2 is compared from identical state only)")}
 
+
+def launch_description(args, world, tr):
+    if args.no_graph or (world > 1 and args.workload == "simnn"):
+        return "eager"
+    if world > 1:
+        return "2 hipGraphs + eager all-reduce per iteration"
+    if getattr(tr, "_graph_gen", None) is not None:
+        return "hipGraph replay: main graph + the generator forward as a graph on a stream of its own"
+    return "hipGraph replay"
+
+
+def measure(args, rank, world, dev, barrier, dist):
+    """Warm up, time exactly args.steps iterations between barriers, then (optionally) the per-launch timing passes of
+    the dominant kernel.  Returns a dict."""
+    import gc
+    from gan_des_midi_music_gen_amd import ops
     tr, step, eager_step, step_eager_same_schedule = (build_simnn if args.workload == "simnn" else build_mmgan)(args, rank, dev)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
     # A generation-2 pass of Python's garbage collector walks every object `import torch` created: a 20-45 ms pause of
     # ONE host call (found with GDM_BENCH_STEP_TIMES=1: one step() of an eager 20-step run took 43.7 ms, the others
-    # 0.35), i.e. 1-2 ms per step of a 20-step timing, at random.  The timed region measures the device path: collect
-    # now, then keep the collector out of it.
-    import gc
+    # 0.35), i.e. 1-2 ms per step of a 20-step timing, at random.  Collect BEFORE the warm-up and keep the collector out
+    # of the warm-up and the timed region: the timed region then follows the warm-up's barrier directly, with the device
+    # still warm (a collection between the two left the device idle for the 20-45 ms it takes).
     gc.collect()
     gc.disable()
-    t0 = time.perf_counter()
-    _dbg = os.environ.get("GDM_BENCH_STEP_TIMES")
-    _ts = []
-    for _ in range(args.steps):
-        _t = time.perf_counter()
-        d_loss, g_loss = step()
+    try:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        _dbg = os.environ.get("GDM_BENCH_STEP_TIMES")
+        _ts = []
+        for _ in range(args.steps):
+            _t = time.perf_counter()
+            step()
+            if _dbg:
+                _ts.append((time.perf_counter() - _t) * 1e3)
         if _dbg:
-            _ts.append((time.perf_counter() - _t) * 1e3)
-    if _dbg:
-        _t = time.perf_counter()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+            _t = time.perf_counter()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()
     if _dbg:
         print("host ms per step:", " ".join(f"{a:.2f}" for a in _ts), " drain", (time.perf_counter() - _t) * 1e3, file=sys.stderr)
     if world > 1:
@@ -348,7 +403,60 @@ def main():
             except Exception:
                 pass
     barrier()
+    res = {"elapsed": elapsed, "losses": losses, "roofline": roofline, "launch": launch_description(args, world, tr)}
+    del tr, step, eager_step, step_eager_same_schedule
+    return res
 
+
+def secondary_lines(args, rank, dev, barrier):
+    """Short measurements of the other configurations the driver's single command should see (one rank only): model 2
+    (BASELINE configs[2]) at B = 256 and at the reference's batch 16, and model 1 in the reference's own precision
+    (exact fp32).  Each: own warm-up, 50 timed replays, own roofline object."""
+    import copy
+    out = {}
+    for name, over in (("mmgan_b256_bf16", dict(workload="mmgan", batch=256, dtype="bf16")),
+                       ("mmgan_b16_bf16", dict(workload="mmgan", batch=16, dtype="bf16")),
+                       ("simnn_b256_fp32", dict(workload="simnn", batch=256, dtype="fp32"))):
+        if over["workload"] == args.workload and over["batch"] == args.batch and over["dtype"] == args.dtype:
+            continue
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        a.steps, a.warmup = 50, 10
+        torch.cuda.empty_cache()
+        r = measure(a, rank, 1, dev, barrier, None)
+        out[name] = {"ms_per_step": round(1e3 * r["elapsed"] / a.steps, 4),
+                     "value": round(a.batch * a.steps / r["elapsed"], 2), "unit": "samples/s", "steps": a.steps,
+                     "warmup": a.warmup, "per_gpu_batch": a.batch, "dtype": "bf16" if a.dtype == "bf16" else "f32",
+                     "launch": r["launch"], "roofline": r["roofline"],
+                     "final_losses": {"disc": round(r["losses"][0], 6), "gen": round(r["losses"][1], 6)}}
+    return out
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))        # before anything touches the GPU in this process
+    if os.environ.get("GDM_BENCH_RENDEZVOUS_ONLY") == "1":
+        return rendezvous_only(args)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    rank, world, local = setup_dist(args.gpus)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    from gan_des_midi_music_gen_amd import _lib
+    if _lib.load().gdm_build_flavor() != 0 and os.environ.get("GDM_BENCH_ALLOW_EXPERIMENT") != "1":   # (A/B runs of variant libraries)
+        raise SystemExit("libgdm_hip.so was built with experiment switches (GDM_HIPCC_FLAGS): rebuild with the shipped "
+                         "flags (`python -m gan_des_midi_music_gen_amd.build`) before benchmarking")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = measure(args, rank, world, dev, barrier, dist)
+    elapsed, losses, roofline = res["elapsed"], res["losses"], res["roofline"]
+    rc = 0
     if rank == 0:
         total = world * args.batch * args.steps
         out = {
@@ -361,26 +469,41 @@ def main():
                              if args.workload == "simnn" else
                              "MMGAN (G + beat-G + D) iteration, MAESTRO-shaped synthetic (2,128,%d) rolls" % args.seq),
                 "per_gpu_batch": args.batch, "global_batch": args.batch * world, "mode": args.mode,
-                "parallelism": f"dp{world}", "launch": ("eager" if (args.no_graph or (world > 1 and args.workload == "simnn")) else
-                           "2 hipGraphs + eager all-reduce per iteration" if world > 1 else
-                           "hipGraph replay: main graph + the generator forward as a graph on a stream of its own"
-                           if (args.workload == "mmgan" or pipelined_flag(args)) else "hipGraph replay"),
+                "parallelism": f"dp{world}", "launch": res["launch"],
                 "iteration": "1 G fwd, 3 D fwd, 2 D bwd, Adam(D)" if
                 args.workload == "simnn" else "2x(G1,G2) fwd, 3 D fwd, 2 D bwd, Adam(D)",
                 **({"schedule": "pipelined: each call = D step of iteration i + generator half (D pass on fake, label 1) "
                                 "of iteration i-1 on a side stream; K timed calls do K of each; results bit-identical "
                                 "to the sequential schedule"}
-                   if args.workload == "simnn" and not args.no_pipeline and not args.no_overlap else {}),
+                   if pipelined_flag(args) else {}),
             },
             "final_losses": {"disc": round(losses[0], 6), "gen": round(losses[1], 6)},
         }
         if roofline is not None:
             out["roofline"] = roofline
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        try:
+            st = json.load(open(tfile)).get(f"{args.workload}_{args.dtype}_step")
+            if st:
+                # whole-iteration HBM bytes (rocprofv3 --pmc, separate passes) over SURVEY.md 8d's algorithmic bytes
+                out["step_traffic_ratio"] = {"measured_bytes_per_step": st["measured_bytes_per_step"],
+                                             "algorithmic_bytes_per_step": st["algorithmic_bytes_per_step"],
+                                             "ratio": round(st["measured_bytes_per_step"] / st["algorithmic_bytes_per_step"], 3),
+                                             "source": st.get("source", "profiles/traffic.json")}
+        except Exception:
+            pass
+        if world == 1 and not args.no_secondary:
+            out["secondary"] = secondary_lines(args, rank, dev, barrier)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"], parity = cpu_baseline(args)
+            out["loss_parity"] = loss_parity(args, parity, dev)
+            if not out["loss_parity"]["pass"]:
+                rc = 3
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

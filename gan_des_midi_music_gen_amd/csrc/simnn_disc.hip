@@ -948,9 +948,6 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(3);
 #endif
-#ifdef GDM_KO_EXPAND        // experiment: expansion only on a strip's first two steps (wrong results)
-    if (rq < rq_first + 1)
-#endif
     bd_expand<T, FUSE, XVEC>(rg, ln, rq, dc_s);
     uint64_t codes[FUSE ? 4 : 1];
     if constexpr (FUSE) {
@@ -999,11 +996,6 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
 #pragma unroll
         for (int rr = 0; rr < ROWS + 2; ++rr) {
           if (rr + 1 < ROWS + 2) row_frags(rr + 1, bb[(rr + 1) & 1]);
-#ifdef GDM_KO_MFMA          // experiment: fragments are read, no matrix products (wrong results)
-#pragma unroll
-          for (int aw = 0; aw < 3; ++aw) acc[rr & 3][aw] += (float)bb[rr & 1][aw][0];
-          continue;
-#endif
 #pragma unroll
           for (int ah = 2; ah >= 0; --ah) {
             const int ir = rr - ah;
@@ -1065,14 +1057,8 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const uint32_t pos = (pf >> (2 * r)) & 3u;
-#ifdef GDM_KO_GATHER      // experiment: no LDS gathers (wrong results)
-            const float f = __builtin_bit_cast(float, pos + 0x3f800000u);
-            xo[r][0] = f; xo[r][1] = f; xo[r][2] = f; xo[r][3] = f;
-            (void)xcol;
-#else
             const float* xp = xcol + 2 * ir * XW + (XW == 256 ? ((pos * 129u) & 0x101u) : (pos & 1u) + XW * (pos >> 1));
             xo[r][0] = xp[0]; xo[r][1] = xp[1]; xo[r][2] = xp[XW]; xo[r][3] = xp[XW + 1];
-#endif
           }
         };
         gather(0, xw[0]);

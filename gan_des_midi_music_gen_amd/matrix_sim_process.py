@@ -17,7 +17,15 @@ numpy's GLOBAL legacy RNG is part of the reference's behaviour (random sources, 
 rounding residue, the per-sample reseed ``np.random.seed(np.random.randint(0, 99999, size=1))``); how much of the
 stream a draw consumes depends on the data, so the draws are made here on the host, per sample, with the same calls in
 the same order -- under the same ``np.random.seed`` the specs are bit-identical to the reference's and the stream ends
-at the same position (tests/golden/des_prologue.npz).  Reference quirks kept: matrix_to_midi ALWAYS draws random
+at the same position (tests/golden/des_prologue.npz).
+
+The reference INTERLEAVES the samples: draws of sample i, ``Sim(...).run`` of sample i -- which consumes the same global
+stream (simulation_v3.py:57,62: ``np.random.choice(self.children, ...)``) from the per-sample seed --, then the draws of
+sample i+1.  ``matrix_to_midi`` / ``matrix_to_wav`` keep that order: the RNG-free scan is ONE batched launch, then per
+sample: draws, a one-sample ``des_routing`` launch, ``simulate(spec)``, next sample (tests/golden/des_prologue_rng.npz:
+recorded with a stand-in Sim that draws from ``np.random`` the way Sim does).  ``midi_prologue`` / ``wav_prologue``
+return ALL specs before any simulation runs (one batched routing launch): equal to the reference only for a back end
+that leaves numpy's global stream alone.  Reference quirks kept: matrix_to_midi ALWAYS draws random
 sources (its emptiness test at line 42 is always true); matrix_to_wav raises ValueError for more than one thresholded
 source (line 30) and IndexError for a thresholded column >= dim (line 67); an all-zero row raises ValueError from
 ``np.random.choice([])``.
@@ -69,43 +77,76 @@ def _check_finite(flags):
         raise ValueError("generated matrix holds non-finite values: the DES prologue is defined for finite inputs only")
 
 
-def midi_prologue(gen1_output, gen2_output, adj_size=(32, 32), instrument=None):
-    """Device-batched head of matrix_to_midi: gen1_output (B,1,S,S), gen2_output (B,n2) device tensors -> [DesSpec]."""
+def _midi_scan(gen1_output, gen2_output, adj_size):
     size = adj_size[0]
     dim = size - 3
     g1 = gen1_output.detach()
     if not g1.is_cuda:
         raise ops.GdmError("matrix_sim_process runs the prologue on a HIP device; move the generator outputs there")
     g1 = g1.float()
-    b = g1.shape[0]
     scan = ops.des_scan(g1, size, dim, note_mod=True)
-    g2 = gen2_output.detach().float().cpu().numpy()
-    inst_h = scan["instruments"].cpu().numpy()
-    notes_h = scan["note_levels"].cpu().numpy()
-    zmask_h = scan["zero_mask"].cpu().numpy()
+    h = {"g1": g1, "size": size, "dim": dim, "b": g1.shape[0],
+         "g2": gen2_output.detach().float().cpu().numpy(), "inst": scan["instruments"].cpu().numpy(),
+         "notes": scan["note_levels"].cpu().numpy(), "zmask": scan["zero_mask"].cpu().numpy()}
     _check_finite(scan["flags"].cpu().numpy())
+    return h
+
+
+def _midi_draws(h, i):
+    """Sample i's draws from numpy's global stream, in the reference's order (lines 43, 101-102, 119-120)."""
+    dim = h["dim"]
+    src = np.zeros(dim, dtype=bool)
+    sources = np.random.choice(dim, size=dim // 4, replace=False)       # line 43 (the test at 42 is always true)
+    src[sources] = True
+    cols = _draw_residue_columns(h["zmask"][i], src, dim)
+    return src, cols, _reseed()
+
+
+def _midi_spec(h, i, routing, src, seeds, instrument):
+    dim = h["dim"]
+    p = h["g2"][i]
+    d_src = (np.abs(p[1] * 50), np.abs(p[2] * 50))
+    d_srv = (np.abs(p[3] * 10), np.abs(p[4] * 10))
+    dist = [["normal", *(d_src if src[k] else d_srv)] for k in range(dim)]
+    instruments = h["inst"][i].astype(np.float64) if instrument is None else np.array([instrument] * dim)
+    return DesSpec(routing, dist, [2 * 127] * dim, seeds, max(200, max(1000, int(3000 * p[6]))), min(float(p[5]), 1.0),
+                   instruments, h["notes"][i].astype(np.float64), np.flatnonzero(src))
+
+
+def _routing(h, lo, hi, src, cols):
+    """des_routing for samples [lo, hi) of the scanned batch: src (n,dim) bool, cols (n,dim) int32 -> (n,dim,dim) f64."""
+    dev = h["g1"].device
+    return ops.des_routing(h["g1"][lo:hi], h["size"], h["dim"],
+                           torch.from_numpy(np.ascontiguousarray(src, dtype=np.uint8)).to(dev),
+                           torch.from_numpy(np.ascontiguousarray(cols, dtype=np.int32)).to(dev)).cpu().numpy()
+
+
+def _batched_specs(h, draws, spec_of):
+    b, dim = h["b"], h["dim"]
     src_all = np.zeros((b, dim), dtype=bool)
     cols_all = np.empty((b, dim), dtype=np.int32)
     seeds = []
     for i in range(b):                                                   # global-RNG order of the reference, per sample
-        sources = np.random.choice(dim, size=dim // 4, replace=False)   # line 43 (the test at 42 is always true)
-        src_all[i, sources] = True
-        cols_all[i] = _draw_residue_columns(zmask_h[i], src_all[i], dim)
-        seeds.append(_reseed())
-    dev = g1.device
-    routing = ops.des_routing(g1, size, dim, torch.from_numpy(src_all.astype(np.uint8)).to(dev),
-                              torch.from_numpy(cols_all).to(dev)).cpu().numpy()
-    specs = []
-    for i in range(b):
-        p = g2[i]
-        d_src = (np.abs(p[1] * 50), np.abs(p[2] * 50))
-        d_srv = (np.abs(p[3] * 10), np.abs(p[4] * 10))
-        dist = [["normal", *(d_src if src_all[i, k] else d_srv)] for k in range(dim)]
-        instruments = inst_h[i].astype(np.float64) if instrument is None else np.array([instrument] * dim)
-        specs.append(DesSpec(routing[i], dist, [2 * 127] * dim, seeds[i],
-                             max(200, max(1000, int(3000 * p[6]))), min(float(p[5]), 1.0), instruments,
-                             notes_h[i].astype(np.float64), np.flatnonzero(src_all[i])))
-    return specs
+        src_all[i], cols_all[i], sd = draws(h, i)
+        seeds.append(sd)
+    routing = _routing(h, 0, b, src_all, cols_all)
+    return [spec_of(h, i, routing[i], src_all[i], seeds[i]) for i in range(b)]
+
+
+def _interleaved_specs(h, draws, spec_of):
+    """The reference's order: a sample's spec is complete (and handed to the caller, who simulates) before the next
+    sample draws anything."""
+    for i in range(h["b"]):
+        src, cols, sd = draws(h, i)
+        routing = _routing(h, i, i + 1, src[None], cols[None])[0]
+        yield spec_of(h, i, routing, src, sd)
+
+
+def midi_prologue(gen1_output, gen2_output, adj_size=(32, 32), instrument=None):
+    """Device-batched head of matrix_to_midi: gen1_output (B,1,S,S), gen2_output (B,n2) device tensors -> [DesSpec].
+    All draws are made before the first spec is returned (see the module docstring)."""
+    h = _midi_scan(gen1_output, gen2_output, adj_size)
+    return _batched_specs(h, _midi_draws, lambda h_, i, r, src, sd: _midi_spec(h_, i, r, src, sd, instrument))
 
 
 def matrix_to_midi(gen1_output, gen2_output, adj_size=(32, 32), instrument=None, start=0, end=150, count=0,
@@ -117,9 +158,10 @@ def matrix_to_midi(gen1_output, gen2_output, adj_size=(32, 32), instrument=None,
         raise ops.GdmError("matrix_to_midi: the DES / MIDI back end is outside this package; pass simulate=callable "
                            "(it receives the DesSpec the reference would construct Sim from)")
     start, end = int(start), int(end)
-    specs = midi_prologue(gen1_output, gen2_output, adj_size, instrument)
-    g2 = gen2_output.detach().float().cpu().numpy()
+    h = _midi_scan(gen1_output, gen2_output, adj_size)
+    g2 = h["g2"]
     midi_rolls, failed = [], 0
+    specs = _interleaved_specs(h, _midi_draws, lambda h_, i, r, src, sd: _midi_spec(h_, i, r, src, sd, instrument))
     for index, spec in enumerate(specs):
         this_count = count if index == 0 else 1
         output = np.zeros((2, 128, end - start))
@@ -132,49 +174,53 @@ def matrix_to_midi(gen1_output, gen2_output, adj_size=(32, 32), instrument=None,
     return midi_rolls, failed
 
 
-def wav_prologue(matrices, size=20, use_same_instrument=None):
-    """Device-batched head of matrix_to_wav: matrices (B,size,size) device tensor -> [DesSpec]."""
+def _wav_scan(matrices, size):
     dim = size - 5
     m = matrices.detach() if isinstance(matrices, torch.Tensor) else torch.as_tensor(np.asarray(matrices))
     if not m.is_cuda:
         raise ops.GdmError("matrix_sim_process runs the prologue on a HIP device; move the generated matrices there")
     m = m.float()
-    b = m.shape[0]
     scan = ops.des_scan(m, size, dim, threshold=0.75, norm_aux=True)
-    thr_h = scan["thr_mask"].cpu().numpy().astype(bool)
-    inst_h, notes_h = scan["instruments"].cpu().numpy(), scan["note_levels"].cpu().numpy()
-    zmask_h, aux_h = scan["zero_mask"].cpu().numpy(), scan["aux"].cpu().numpy()
+    h = {"g1": m, "size": size, "dim": dim, "b": m.shape[0], "thr": scan["thr_mask"].cpu().numpy().astype(bool),
+         "inst": scan["instruments"].cpu().numpy(), "notes": scan["note_levels"].cpu().numpy(),
+         "zmask": scan["zero_mask"].cpu().numpy(), "aux": scan["aux"].cpu().numpy()}
     _check_finite(scan["flags"].cpu().numpy())
-    src_all = np.zeros((b, dim), dtype=bool)
-    cols_all = np.empty((b, dim), dtype=np.int32)
-    seeds = []
-    for i in range(b):
-        hit = np.flatnonzero(thr_h[i])
-        if len(hit) == 0:
-            sources = np.random.choice(dim, size=size // 8, replace=False)     # line 27
-        elif len(hit) == 1:
-            sources = hit
-        else:
-            raise ValueError("The truth value of an array with more than one element is ambiguous (matrix_to_wav keeps "
-                             "np.where's tuple: more than one thresholded source cannot be processed, line 30)")
-        if sources.max() >= dim:
-            raise IndexError(f"index {int(sources.max())} is out of bounds for axis 1 with size {dim}")   # line 67
-        src_all[i, sources] = True
-        cols_all[i] = _draw_residue_columns(zmask_h[i], src_all[i], dim)
-        seeds.append(_reseed())
-    dev = m.device
-    routing = ops.des_routing(m, size, dim, torch.from_numpy(src_all.astype(np.uint8)).to(dev),
-                              torch.from_numpy(cols_all).to(dev)).cpu().numpy()
-    specs = []
-    for i in range(b):
-        r3, r4 = aux_h[i, 0], aux_h[i, 1]
-        dist = [["normal", 30 * r3[k], 15 * r4[k]] if src_all[i, k] else ["normal", 5 * r3[k], 3 * r4[k]]
-                for k in range(dim)]
-        instruments = inst_h[i].astype(np.float64) if use_same_instrument is None else \
-            np.array([use_same_instrument] * dim)
-        specs.append(DesSpec(routing[i], dist, [2 * 127] * dim, seeds[i], 1000, 0.5, instruments,
-                             notes_h[i].astype(np.float64), np.flatnonzero(src_all[i])))
-    return specs
+    return h
+
+
+def _wav_draws(h, i):
+    dim, size = h["dim"], h["size"]
+    hit = np.flatnonzero(h["thr"][i])
+    if len(hit) == 0:
+        sources = np.random.choice(dim, size=size // 8, replace=False)     # line 27
+    elif len(hit) == 1:
+        sources = hit
+    else:
+        raise ValueError("The truth value of an array with more than one element is ambiguous (matrix_to_wav keeps "
+                         "np.where's tuple: more than one thresholded source cannot be processed, line 30)")
+    if sources.max() >= dim:
+        raise IndexError(f"index {int(sources.max())} is out of bounds for axis 1 with size {dim}")   # line 67
+    src = np.zeros(dim, dtype=bool)
+    src[sources] = True
+    cols = _draw_residue_columns(h["zmask"][i], src, dim)
+    return src, cols, _reseed()
+
+
+def _wav_spec(h, i, routing, src, seeds, use_same_instrument):
+    dim = h["dim"]
+    r3, r4 = h["aux"][i, 0], h["aux"][i, 1]
+    dist = [["normal", 30 * r3[k], 15 * r4[k]] if src[k] else ["normal", 5 * r3[k], 3 * r4[k]] for k in range(dim)]
+    instruments = h["inst"][i].astype(np.float64) if use_same_instrument is None else \
+        np.array([use_same_instrument] * dim)
+    return DesSpec(routing, dist, [2 * 127] * dim, seeds, 1000, 0.5, instruments, h["notes"][i].astype(np.float64),
+                   np.flatnonzero(src))
+
+
+def wav_prologue(matrices, size=20, use_same_instrument=None):
+    """Device-batched head of matrix_to_wav: matrices (B,size,size) device tensor -> [DesSpec].  All draws are made
+    before the first spec is returned (see the module docstring)."""
+    h = _wav_scan(matrices, size)
+    return _batched_specs(h, _wav_draws, lambda h_, i, r, src, sd: _wav_spec(h_, i, r, src, sd, use_same_instrument))
 
 
 def matrix_to_wav(matrices, size=20, use_same_instrument=None, start=0, end=174, device="cpu", simulate=None):
@@ -183,6 +229,7 @@ def matrix_to_wav(matrices, size=20, use_same_instrument=None, start=0, end=174,
     tensor on ``device``."""
     if simulate is None:
         raise ops.GdmError("matrix_to_wav: the DES / FluidSynth back end is outside this package; pass simulate=callable")
-    specs = wav_prologue(matrices, size, use_same_instrument)
+    h = _wav_scan(matrices, size)
+    specs = _interleaved_specs(h, _wav_draws, lambda h_, i, r, src, sd: _wav_spec(h_, i, r, src, sd, use_same_instrument))
     spectrograms = [torch.as_tensor(simulate(spec, index=i)) for i, spec in enumerate(specs)]
     return torch.stack([s[:, start:end] for s in spectrograms]).to(device)

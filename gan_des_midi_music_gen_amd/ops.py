@@ -3,7 +3,9 @@
 PyTorch is used here only for device memory (caching allocator) and the current HIP stream; every wrapper checks
 that its tensors live on a HIP device and raises otherwise -- there is no CPU path.
 """
+import contextlib
 import ctypes
+import threading
 
 import torch
 
@@ -75,17 +77,33 @@ def _call(name, *args):
 _ws_cache = {}
 _ws_retired = []          # superseded buffers a captured hipGraph may still point into (never freed)
 _ws_pinned = set()        # keys that were used while a stream capture was in progress
+_ws_ns = threading.local()
+
+
+@contextlib.contextmanager
+def workspace_namespace(ns):
+    """Scratch buffers handed out inside this context belong to ``ns`` (any hashable) instead of being shared by
+    everything that runs on the same stream.  Every hipGraph capture gets a namespace of its own: torch captures all
+    graphs on ONE shared side stream, so without it two graphs that are later replayed CONCURRENTLY (a trainer's main
+    graph and its generator graph, on different streams) would have the same scratch buffer baked in."""
+    prev = getattr(_ws_ns, "ns", None)
+    _ws_ns.ns = ns
+    try:
+        yield
+    finally:
+        _ws_ns.ns = prev
 
 
 def workspace(nbytes, device):
-    """Grow-only scratch buffer per (device, stream); safe because every consumer is ordered on the same stream.
+    """Grow-only scratch buffer per (device, stream, namespace); safe because every consumer is ordered on the same
+    stream (and graphs that may run side by side capture under different namespaces, see workspace_namespace).
 
     A captured hipGraph has the address of the buffer it saw baked in, so a buffer that was handed out during a capture
     is never released: when a later call (eager, or later in the same capture) needs more room, the old buffer is
     retired -- kept alive, so the graph keeps writing into memory that is still ours -- and a larger one takes its
     place.  (Freeing it, as the first version did, let the allocator hand the same bytes to another tensor of the
     graph.)"""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, getattr(_ws_ns, "ns", None))
     capturing = torch.cuda.is_current_stream_capturing()
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:

@@ -14,8 +14,6 @@ MMGAN_MIDI_DES/network_tests.py:281-321), restructured for MI355X:
 Generators are never updated by the reference loops (no gradient crosses the DES bridge); only their BatchNorm
 running statistics move, once (model 1) or twice (model 2) per iteration.
 """
-import os
-
 import torch
 
 from . import dp
@@ -496,9 +494,15 @@ class SimnnTrainer(_TrainerBase):
         return self.loss_g
 
     # ---- hipGraph capture of the whole iteration for fixed input buffers -------------------------------------------
-    def capture(self, real, noise, fake, pipelined=False):
+    def capture(self, real, noise, fake, pipelined=False, generator_graph=True):
         """Record one iteration on (real, noise, fake) -- tensors whose storage is re-used for every replay -- into a
-        hipGraph.  Not available with a callable bridge or with more than one rank."""
+        hipGraph.  Not available with a callable bridge or with more than one rank.
+
+        pipelined + generator_graph (the default): the generator forward (6 launches that feed nothing inside the
+        iteration) is a graph of its OWN, replayed on a stream of the trainer's own beside the main graph: as a branch
+        of the main graph its fork and join were cross-queue dependencies inside the iteration (0.699 -> 0.684 ms;
+        generator_graph=False keeps it inside the main graph).  The two graphs run concurrently, so each is captured
+        under a scratch-buffer namespace of its own (ops.workspace_namespace)."""
         if callable(fake) or self.world > 1:
             raise ops.GdmError("graph capture needs tensor inputs and a single rank")
         self._static = (Fn._f32c(real), noise, Fn._f32c(fake))
@@ -511,23 +515,18 @@ class SimnnTrainer(_TrainerBase):
         torch.cuda.current_stream().wait_stream(warm)
         torch.cuda.synchronize()
         self._graph_gen = None
-        if pipelined and os.environ.get("GDM_EXP_GEN_GRAPH", "1") == "1":
-            # The generator forward (6 launches that feed nothing inside the iteration) is a graph of its OWN, replayed
-            # on a stream of the trainer's own beside this iteration's main graph: as a branch of the main graph its fork
-            # and join were cross-queue dependencies inside the iteration (0.699 -> 0.684 ms).  The caller's stream waits
-            # for it after the main graph (it is much the shorter one).
+        self._graph = torch.cuda.CUDAGraph()
+        if pipelined and generator_graph:
             ws, bns = self._gen_state()
             self._graph_gen = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_gen):
+            with ops.workspace_namespace(("graph", id(self._graph_gen))), torch.cuda.graph(self._graph_gen):
                 self._last_generated, _gs = Fn.simnn_gen_forward(self._static[1], ws, bns, self.gen.training, self.dt,
                                                                  cache=self._tm_cache, need_backward=False)
             self._gen_replay_stream = torch.cuda.Stream(real.device)
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with ops.workspace_namespace(("graph", id(self._graph))), torch.cuda.graph(self._graph):
                 self.step_pipelined(*self._static, with_generator=False)   # finds a pending half and leaves one
         else:
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with ops.workspace_namespace(("graph", id(self._graph))), torch.cuda.graph(self._graph):
                 fn(*self._static)
         self.d.step_count -= 1     # the captured call did not execute: the device-side step counter did not move
         self.iterations -= 1
@@ -626,6 +625,12 @@ class MmganTrainer(_TrainerBase):
     def _fused_ok(self, t):
         return self.dt == ops.BF16 and ops.dcnn_fused_supported(t)
 
+    def _gen_fused_ok(self, b):
+        """Whether an iteration's generator work takes the fused chain (staged inputs + one launch per block depth)."""
+        mm = self.mm
+        return (self.dt == ops.BF16 and 1 < b <= ops.linear_bn_act_max_rows() and mm.generator1.training
+                and mm.generator2.training)
+
     def _gen_inputs(self, noise1, noise2, beats, g1_in_a, g1_in_b):
         """The generators' input rows [noise | conditioning] (network_tests.py:87, 119) in one launch: x1 (2B rows: the
         two forwards of generator 1), x2 (B rows).  The ONLY reader of the caller's noise / beat tensors."""
@@ -646,8 +651,7 @@ class MmganTrainer(_TrainerBase):
         Returns (g1_a, g2_a, g1_b, g2_b); falls back to two sequential forwards where the fused block does not apply."""
         mm, dt = self.mm, self.dt
         b = len(noise1)
-        fused = (dt == ops.BF16 and 1 < b <= ops.linear_bn_act_max_rows() and mm.generator1.training
-                 and mm.generator2.training)
+        fused = self._gen_fused_ok(b)
         if not fused:
             g1a, g2a = self._generators_forward(noise1, noise2, beats, g1_in_a, streams)
             g1b, g2b = self._generators_forward(noise1, noise2, beats, g1_in_b, streams)
@@ -780,6 +784,13 @@ class MmganTrainer(_TrainerBase):
         if fused:
             ops.dcnn_pack(w1, b1, w2, b2, wf, bf, t, out=self._pack)     # weights changed: refresh in place
         if callable(fake_b):
+            if getattr(self, "_gen_join_pending", False):
+                # mixed bridge (tensor fake_a, callable fake_b): the generator chains were forked late and are still
+                # running on their side streams -- the bridge reads their outputs on this stream
+                main = torch.cuda.current_stream()
+                for sd in self._sides(piano_roll.device):
+                    main.wait_stream(sd)
+                self._gen_join_pending = False
             fake_b = fake_b(*self._gen_b)      # the generators' second forward ran at the start of the iteration
         if fused:
             if self.elide:
@@ -832,27 +843,37 @@ class MmganTrainer(_TrainerBase):
             # the discriminator chain (the generators' graph is the shorter one).
             # (the generators' graph is two: the one-launch input staging, the only reader of the caller's tensors, and
             # the four block launches -- the caller's stream waits for the FIRST only, see replay)
-            self._graph_gen_in = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_gen_in):
-                staged = self._gen_inputs(noise1, noise2, beats, g1_in_a, g1_in_b)
+            # Only the fused generator chain reads the staged rows; the fallback chain (fp32, B > the fused block's row
+            # limit, eval-mode generators) concatenates the caller's tensors itself, inside the block graph -- then
+            # there is no staging graph and ``replay`` makes the caller's stream wait for the WHOLE generator graph
+            # before a refill of the inputs may follow.
+            self._gen_staged = self._gen_fused_ok(len(noise1))
+            self._graph_gen_in = None
             self._graph_gen = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_gen, pool=self._graph_gen_in.pool()):
+            self._graph = torch.cuda.CUDAGraph()
+            ns_gen, ns_main = ("graph", id(self._graph_gen)), ("graph", id(self._graph))
+            staged, pool = None, None
+            if self._gen_staged:
+                self._graph_gen_in = torch.cuda.CUDAGraph()
+                with ops.workspace_namespace(ns_gen), torch.cuda.graph(self._graph_gen_in):
+                    staged = self._gen_inputs(noise1, noise2, beats, g1_in_a, g1_in_b)
+                pool = self._graph_gen_in.pool()
+            with ops.workspace_namespace(ns_gen), torch.cuda.graph(self._graph_gen, pool=pool):
                 g1, g2, g1b, g2b = self._generators_forward_both(noise1, noise2, beats, g1_in_a, g1_in_b, None,
                                                                  staged=staged)
                 self._last_g1, self._last_g2 = g1, g2
                 self._gen_b = (g1b, g2b)
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            with ops.workspace_namespace(ns_main), torch.cuda.graph(self._graph):
                 self._part_a(piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a, g1_in_b,
                              with_generators=False)
                 self._part_b(piano_roll, beats, noise1, noise2, fake_b, g1_in_b)
             self._gen_replay_stream = torch.cuda.Stream(piano_roll.device)
         else:
             ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            with ops.workspace_namespace(("graph", id(ga))), torch.cuda.graph(ga):
                 self._part_a(piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a, g1_in_b)
             pool = ga.pool()
-            with torch.cuda.graph(gb, pool=pool):
+            with ops.workspace_namespace(("graph", id(ga))), torch.cuda.graph(gb, pool=pool):   # (sequential: shared)
                 self._part_b(piano_roll, beats, noise1, noise2, fake_b, g1_in_b)
             self._graph = (ga, gb)
         self.d.step_count -= 1     # the captured call did not execute: the device-side step counter did not move
@@ -871,15 +892,18 @@ class MmganTrainer(_TrainerBase):
             sg = self._gen_replay_stream
             sg.wait_stream(main)
             with torch.cuda.stream(sg):
-                self._graph_gen_in.replay()
-                staged_ev = sg.record_event()
+                staged_ev = None
+                if self._graph_gen_in is not None:
+                    self._graph_gen_in.replay()
+                    staged_ev = sg.record_event()
                 self._graph_gen.replay()
                 self._gen_event = sg.record_event()
             self._graph.replay()
             # whatever the caller enqueues next (a refill of the inputs, the next replay) comes after the generators'
             # READS of the caller's tensors: the one staging launch at the head of their stream.  (Waiting for their whole
-            # graph cost 4 % at B = 256 and 17 % at B = 16, where the generators' chain is the longer one.)
-            main.wait_event(staged_ev)
+            # graph cost 4 % at B = 256 and 17 % at B = 16, where the generators' chain is the longer one.)  Without a
+            # staging graph (fallback generator chain) the block graph itself reads them: wait for all of it.
+            main.wait_event(staged_ev if staged_ev is not None else self._gen_event)
         self.d.step_count += 1
         self.iterations += 1
         return self.loss_d, self.loss_g

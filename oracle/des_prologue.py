@@ -48,9 +48,10 @@ def _reseed():
     return np.random.randint(0, 99999, size=1)
 
 
-def midi_prologue(gen1_output, gen2_output, adj_size=(32, 32), instrument=None):
+def midi_prologue(gen1_output, gen2_output, adj_size=(32, 32), instrument=None, on_spec=None):
     """gen1_output (B,1,S,S), gen2_output (B,n2) float32 arrays -> list of dicts (one per sample) with the arguments of
-    Sim(...) / Sim.run / process_adjsim_log."""
+    Sim(...) / Sim.run / process_adjsim_log.  ``on_spec(spec)`` is called where the reference runs the simulation of
+    that sample (lines 150-163) -- BEFORE the next sample's draws: Sim consumes the same global numpy stream."""
     g1 = np.asarray(gen1_output, dtype=np.float32)
     g2 = np.asarray(gen2_output, dtype=np.float32)
     size = adj_size[0]
@@ -73,11 +74,14 @@ def midi_prologue(gen1_output, gen2_output, adj_size=(32, 32), instrument=None):
         specs.append({"sim_matrix": sim, "distributions": dist, "queue_list": [2 * 127] * dim, "seeds": seeds,
                       "num_customers": max(200, max(1000, int(3000 * p[6]))), "max_sim_time": min(float(p[5]), 1.0),
                       "instruments": instruments, "note_levels": note_levels})
+        if on_spec is not None:
+            on_spec(specs[-1])
     return specs
 
 
-def wav_prologue(matrices, size=20, use_same_instrument=None):
-    """matrices (B,size,size) float32 -> list of dicts like midi_prologue (max_sim_time 0.5, 1000 customers)."""
+def wav_prologue(matrices, size=20, use_same_instrument=None, on_spec=None):
+    """matrices (B,size,size) float32 -> list of dicts like midi_prologue (max_sim_time 0.5, 1000 customers);
+    ``on_spec`` as in midi_prologue (lines 108-110)."""
     ms = np.asarray(matrices, dtype=np.float32)
     dim = size - 5
     specs = []
@@ -104,4 +108,6 @@ def wav_prologue(matrices, size=20, use_same_instrument=None):
         specs.append({"sim_matrix": sim, "distributions": dist, "queue_list": [2 * 127] * dim, "seeds": seeds,
                       "num_customers": 1000, "max_sim_time": 0.5, "instruments": instruments,
                       "note_levels": note_levels})
+        if on_spec is not None:
+            on_spec(specs[-1])
     return specs

@@ -135,3 +135,37 @@ def test_prologue_edge_cases():
         msp.midi_prologue(bad, torch.rand(1, 20, device=DEV), adj_size=(64, 64))
     with pytest.raises(ops.GdmError):
         msp.midi_prologue(torch.rand(1, 1, 64, 64), torch.rand(1, 20), adj_size=(64, 64))      # CPU tensors: no fallback
+
+
+def test_bridges_interleave_prologue_and_simulator_draws_like_the_reference():
+    """tests/golden/des_prologue_rng.npz (recorded from the reference with a stand-in Sim whose run() draws from
+    np.random, as simulation_v3.Sim does): matrix_to_midi / matrix_to_wav must hand sample i to ``simulate`` before
+    they draw for sample i+1 -- specs, simulation draws and the final stream position are the reference's."""
+    from test_oracle_golden import sim_like_draws
+    g = load_golden("des_prologue_rng.npz")
+    draws, seen = [], []
+
+    def sim_midi(spec, **kw):
+        seen.append(spec)
+        draws.append(sim_like_draws(spec.sim_matrix))
+
+    np.random.seed(int(g["midi/np_seed"]))
+    msp.matrix_to_midi(torch.from_numpy(g["midi/g1"][:, None]).to(DEV), torch.from_numpy(g["midi/g2"]).to(DEV),
+                       adj_size=(64, 64), instrument=None, start=100, end=150, count=1, simulate=sim_midi)
+    assert np.random.randint(0, 2 ** 31 - 1) == int(g["midi/rng_after"])
+    for b, (want, spec) in enumerate(zip(_golden_specs(g, "midi"), seen)):
+        _same(spec, want, ("midi-rng", b))
+    assert np.array_equal(np.concatenate(draws), g["midi/sim_draws"])
+    draws, seen = [], []
+
+    def sim_wav(spec, index):
+        seen.append(spec)
+        draws.append(sim_like_draws(spec.sim_matrix))
+        return torch.zeros(128, 216)
+
+    np.random.seed(int(g["wav/np_seed"]))
+    msp.matrix_to_wav(torch.from_numpy(g["wav/matrices"]).to(DEV), size=20, start=0, end=216, simulate=sim_wav)
+    assert np.random.randint(0, 2 ** 31 - 1) == int(g["wav/rng_after"])
+    for b, (want, spec) in enumerate(zip(_golden_specs(g, "wav"), seen)):
+        _same(spec, want, ("wav-rng", b))
+    assert np.array_equal(np.concatenate(draws), g["wav/sim_draws"])

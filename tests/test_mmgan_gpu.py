@@ -362,21 +362,25 @@ def test_graph_replay_matches_eager_bf16():
     assert outs[0][3] == outs[1][3] == 10
 
 
-def test_replay_with_refilled_inputs_matches_eager_steps():
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_replay_with_refilled_inputs_matches_eager_steps(dtype):
     """One rank replays two graphs (discriminator chain; generators on the trainer's own stream): refilling the static
     inputs between replays without any synchronisation must reproduce eager steps on the same sequence of batches,
-    generator outputs included."""
+    generator outputs included.  fp32: the generators take the fallback chain -- no staging launch, the block graph
+    itself reads the caller's tensors (replay must then wait for ALL of it before a refill), and both graphs use
+    scratch buffers (each has its own namespace)."""
     b, n = 32, 6
     batches = [synthetic.mmgan_inputs(b, 50, seed=400 + i, device=DEV) for i in range(n)]
     keys = ("piano_roll", "durations", "beats", "noise1", "noise2", "fake_a", "fake_b", "g1_in_a", "g1_in_b")
     runs = []
     for mode in ("eager", "graph"):
         mm = _mm(17).to(DEV)
-        tr = MmganTrainer(mm, lr=0.01, compute_dtype="bf16")
+        tr = MmganTrainer(mm, lr=0.01, compute_dtype=dtype)
         outs = []
         if mode == "graph":
             st = {k: batches[0][k].clone() for k in keys}
             tr.capture(*[st[k] for k in keys])                        # 2 warm-up iterations on batch 0
+            assert (tr._graph_gen_in is not None) == (dtype == "bf16")
             for i in range(2, n):
                 for k in keys:
                     st[k].copy_(batches[i][k])

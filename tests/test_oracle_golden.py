@@ -260,3 +260,34 @@ def test_des_prologue_oracle_reproduces_the_recorded_sim_arguments():
     assert str(g["wav/two_sources_raises"]) == "ValueError"
     with pytest.raises(ValueError):
         odp.wav_prologue(two, size=20)
+
+
+def sim_like_draws(sim_matrix):
+    """What the RNG-consuming stand-in Sim of tests/golden/make_golden.py (_SimRecorderRng.run) draws from numpy's
+    global stream for one sample."""
+    n = 3 + int(np.abs(np.asarray(sim_matrix)[0]).argmax()) % 4
+    return np.array([np.random.choice(5, p=[0.1, 0.2, 0.3, 0.15, 0.25]) for _ in range(n)] + [np.random.choice(7)])
+
+
+def test_des_prologue_oracle_interleaves_with_a_simulator_that_draws():
+    """des_prologue_rng.npz: the reference functions ran with a stand-in Sim whose run() consumes np.random like
+    simulation_v3.Sim (simulation_v3.py:57,62).  The specs of samples >= 1 then depend on the simulation draws of the
+    samples before them: the oracle reproduces every spec, every simulation draw and the final stream position only if
+    it hands sample i to the simulator before drawing for sample i+1."""
+    from oracle import des_prologue as odp
+    g = load_golden("des_prologue_rng.npz")
+    for pre, run in (("midi", lambda cb: odp.midi_prologue(g["midi/g1"][:, None], g["midi/g2"], adj_size=(64, 64),
+                                                           on_spec=cb)),
+                     ("wav", lambda cb: odp.wav_prologue(g["wav/matrices"], size=20, on_spec=cb))):
+        draws = []
+        np.random.seed(int(g[f"{pre}/np_seed"]))
+        specs = run(lambda sp: draws.append(sim_like_draws(sp["sim_matrix"])))
+        assert np.random.randint(0, 2 ** 31 - 1) == int(g[f"{pre}/rng_after"])
+        _check_des_specs(specs, g, pre)
+        assert [len(d) for d in draws] == list(g[f"{pre}/sim_draw_counts"])
+        assert np.array_equal(np.concatenate(draws), g[f"{pre}/sim_draws"])
+        # and the batched order (all prologue draws first) is NOT the reference's once the simulator draws
+        np.random.seed(int(g[f"{pre}/np_seed"]))
+        specs_b = (odp.midi_prologue(g["midi/g1"][:, None], g["midi/g2"], adj_size=(64, 64)) if pre == "midi"
+                   else odp.wav_prologue(g["wav/matrices"], size=20))
+        assert not np.array_equal(specs_b[1]["sim_matrix"], g[f"{pre}/sim_matrix"][1])

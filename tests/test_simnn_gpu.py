@@ -288,16 +288,21 @@ def test_pipelined_iterations_are_bit_identical_to_sequential(dtype):
     assert tr._pending_fake is None
 
 
-def test_pipelined_graph_replay_matches_sequential_steps():
-    hw, b = (128, 216), 4
+@pytest.mark.parametrize("dtype,b,hw", [("bf16", 4, (128, 216)), ("fp32", 4, (32, 40)), ("bf16", 260, (32, 40))])
+def test_pipelined_graph_replay_matches_sequential_steps(dtype, b, hw):
+    """The main graph and the generator graph replay CONCURRENTLY on two streams.  In fp32 mode (layer-wise generator:
+    split-K GEMM, bn_act_fwd) and for B > 256 (bn_stats) the generator graph uses scratch buffers too: each graph must
+    have its own (ops.workspace_namespace), or the two race -- losses, weights, generated matrices and the generator's
+    BatchNorm statistics are compared bit for bit with sequential eager steps."""
     outs = []
     for mode in ("seq", "graph"):
-        gen, disc = _build(7, True)
+        gen, disc = _build(7, True, input_hw=hw)
         gen.to(DEV), disc.to(DEV)
-        tr = SimnnTrainer(gen, disc, compute_dtype="bf16")
+        tr = SimnnTrainer(gen, disc, compute_dtype=dtype)
         real, fake, noise = synthetic.simnn_inputs(b, hw, seed=55, device=DEV)
         if mode == "graph":
             tr.capture(real, noise, fake, pipelined=True)       # 2 warm-up calls run; the captured call does not
+            assert tr._graph_gen is not None
             for _ in range(3):
                 dl, _ = tr.replay()
             gl = tr.flush()
@@ -305,9 +310,11 @@ def test_pipelined_graph_replay_matches_sequential_steps():
             for _ in range(5):
                 dl, gl = tr.step(real, noise, fake)
         torch.cuda.synchronize()
-        outs.append((dl.item(), gl.item(), disc.fc1.weight.detach().clone(), disc.conv2.weight.detach().clone()))
+        outs.append((dl.item(), gl.item(), disc.fc1.weight.detach().clone(), disc.conv2.weight.detach().clone(),
+                     tr.last_generated.clone(), gen.batch_norm1.running_var.clone(), gen.batch_norm3.running_mean.clone()))
     assert outs[0][0] == outs[1][0] and outs[0][1] == outs[1][1], (outs[0][:2], outs[1][:2])
-    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+    for k in range(2, 7):
+        assert torch.equal(outs[0][k], outs[1][k]), k
 
 
 def test_pipelined_replay_with_refilled_inputs_matches_eager_steps():
