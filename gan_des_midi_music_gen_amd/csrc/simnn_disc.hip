@@ -56,6 +56,11 @@ struct Stamps {
 
 constexpr int COLS = 64;   // conv-output columns handled per workgroup (column super-tile)
 
+// index (in 16-bit fields) of code1's field for pooled pixel pw of row `row` (= image * H1 + pooled row), group g
+__device__ __forceinline__ uint32_t code1_field(uint32_t row, int Q1, int pw, int g) {
+  return ((row * (uint32_t)Q1 + (uint32_t)(pw >> 2)) * 4u + (uint32_t)g) * 4u + (uint32_t)(pw & 3);
+}
+
 template <typename T> struct Px;  // LDS pixel-record strides (elements) for 16- and 32-channel records
 template <> struct Px<float> { static constexpr int S16 = 17, S32 = 33; };
 template <> struct Px<__bf16> { static constexpr int S16 = 16, S32 = 32; };
@@ -121,9 +126,14 @@ __device__ __forceinline__ void buf_store2(rsrc_t r, uint32_t off, uint32_t v) {
 
 // =====================================================================================================================
 // conv1 forward: Conv2d(1,16,k2,s1,p1) + ReLU + MaxPool2d(2)
-// code1 (uint64 per pooled pixel) = four 16-bit fields, field g for channels 4g..4g+3:
-//   bits [2r+1:2r] = argmax position of channel 4g+r (dy*2+dx, first max in scan order like
-//   aten::max_pool2d_with_indices), bit 8+r = channel is live (pooled value > 0, i.e. ReLU passes gradient).
+// code1 = one 16-bit field per (pooled pixel, 4-channel group g): nibble k (bits 4k..4k+3) belongs to channel 4g+k:
+//   bits [1:0] = argmax position (dy*2+dx, first max in scan order like aten::max_pool2d_with_indices),
+//   bit 2 = channel is live (pooled value > 0, i.e. ReLU passes gradient), bit 3 = 0.
+// Fields are stored "quad-major": [image][pooled row][quad = pw / 4][group g][pw % 4], Q1 = ceil(W1 / 4) quads per row
+// (8 bytes per pixel).  The forward's lane (pixel, group) writes one field, as before; in the fused backward a lane owns
+// ONE channel and FOUR neighbouring pixels (the transposed MFMA result), and the four fields of its channel group are
+// then 8 contiguous bytes -- one load, no cross-lane transpose on either side.  Pixels >= W1 of a row's last quad
+// hold 0 (dead).
 //
 // The 2x2 stencil is a [16 channels x 4 taps] x [4 taps x pixels] product: one exact-fp32 v_mfma_f32_16x16x4_f32 per
 // pooling position and 16 pooled pixels, bias as the accumulator's initial value.  A wave takes units of 16 pooled
@@ -135,14 +145,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, int B, int H, int W, int H1,
                                                         int W1, int n_rows, T* __restrict__ p1,
-                                                        uint64_t* __restrict__ code1) {
+                                                        uint16_t* __restrict__ code1) {
   const int t = threadIdx.x, l = t & 63, lr = l & 15, lg = l >> 4;
+  const int Q1 = (W1 + 3) >> 2;
   // the wave index is uniform: keep everything derived from it in scalar registers
   const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (t >> 6)), n_waves = gridDim.x * 4;
   const int upr = (W1 + 15) >> 4;                            // units per pooled row
   const rsrc_t xr = make_rsrc(x, (uint32_t)B * H * W * 4);
   const rsrc_t pr = make_rsrc(p1, (uint32_t)B * H1 * W1 * 16 * sizeof(T));
-  const rsrc_t cr = make_rsrc(code1, (uint32_t)B * H1 * W1 * 8);
+  const rsrc_t cr = make_rsrc(code1, (uint32_t)B * H1 * Q1 * 32);
   // A operand: lane (row = channel lr, k = tap lg); accumulator rows 4lg + r = channels
   const float aw = w[lr * 4 + lg];
   const f32x4 b4 = {bias[4 * lg], bias[4 * lg + 1], bias[4 * lg + 2], bias[4 * lg + 3]};
@@ -157,12 +168,13 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
   // depends on the row (base offsets, row-interior flag, validity) is recomputed only when a slot moves to its next
   // row, behind a scalar branch.  (Per-unit position arithmetic with carries cost ~100 SALU instructions per unit --
   // more than the unit's VALU work; the CU's single scalar unit was the limiter.)
-  struct Slot { int seg, ph, b; uint32_t xrow, pixrow; bool interior, valid; };
+  struct Slot { int seg, ph, b; uint32_t xrow, pixrow, crow; bool interior, valid; };
   const int dph = n_waves % H1, db = n_waves / H1;
   auto set_row = [&](Slot& q) {
     const int b = min(q.b, B - 1);                           // past the end: re-read the last image (stores are dropped)
     q.xrow = (uint32_t)(((b * H + 2 * q.ph) * W) * 4);
     q.pixrow = (uint32_t)((b * H1 + q.ph) * W1);
+    q.crow = (uint32_t)(b * H1 + q.ph);
     q.interior = q.ph > 0 && 2 * q.ph + 1 < H;
     q.valid = q.b < B;
   };
@@ -209,8 +221,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       pos = v1 == m ? 1u : pos;
       pos = v0 == m ? 0u : pos;
       best[r] = fmaxf(m, 0.f);
-      field |= pos << (2 * r);
-      field |= (m > 0.f ? 1u : 0u) << (8 + r);
+      field |= (m > 0.f ? pos | 4u : pos) << (4 * r);
     }
     const int pw = 16 * q.seg + lr;
     const uint32_t pix = q.pixrow + (uint32_t)pw;
@@ -223,7 +234,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     } else {
       buf_store16(pr, ok ? pix * 64u + 16u * lg : BUF_OOB, (f32x4){best[0], best[1], best[2], best[3]});
     }
-    buf_store2<GDM_ACT_STORE_AUX2>(cr, ok ? pix * 8u + 2u * lg : BUF_OOB, field);
+    // the whole last quad is written (zeros beyond W1): its consumers load four pixels' fields at once
+    buf_store2<GDM_ACT_STORE_AUX2>(cr, (q.valid && pw < 4 * Q1) ? code1_field(q.crow, Q1, pw, lg) * 2u : BUF_OOB,
+                                   ok ? field : 0u);
   };
   if (wave >= n_rows) return;
   // DEPTH units in flight per wave; every trip issues the same loads and stores (units past the end re-read valid
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 // =====================================================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restrict__ dp1,
-                                                               const uint64_t* __restrict__ code1,
+                                                               const uint16_t* __restrict__ code1,
                                                                const float* __restrict__ x, int B, int H, int W,
                                                                int H1, int W1, float* __restrict__ slabs) {
   __shared__ float red[4][80];
@@ -278,14 +291,16 @@ __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restri
         in[r][s] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? xb[(int64_t)ih * W + iw] : 0.f;
       }
     }
-    const uint64_t code = code1[idx];
+    uint32_t fields[4];                                                         // code1 format: see conv1_fwd_kernel
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) fields[g4] = code1[code1_field((uint32_t)(b * H1 + ph), (W1 + 3) >> 2, pw, g4)];
     const T* g16 = dp1 + idx * 16;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      const uint32_t field = (uint32_t)(code >> (16 * (c >> 2))) & 0xffffu;     // code1 format: see conv1_fwd_kernel
-      const bool live = (field >> (8 + (c & 3))) & 1;
+      const uint32_t nib = fields[c >> 2] >> (4 * (c & 3));
+      const bool live = (nib >> 2) & 1;
       const float g = live ? to_f32(g16[c]) : 0.f;
-      const int pos = (int)((field >> (2 * (c & 3))) & 3);
+      const int pos = (int)(nib & 3);
       const bool dy = pos >> 1, dx = pos & 1;
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
@@ -320,7 +335,7 @@ __global__ __launch_bounds__(256) void conv1_bwd_weight_kernel(const T* __restri
 // =====================================================================================================================
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_bwd_data_kernel(const T* __restrict__ dp1,
-                                                             const uint64_t* __restrict__ code1,
+                                                             const uint16_t* __restrict__ code1,
                                                              const float* __restrict__ w, int B, int H, int W, int H1,
                                                              int W1, float* __restrict__ dx) {
   __shared__ float ws[64];
@@ -338,13 +353,15 @@ __global__ __launch_bounds__(256) void conv1_bwd_data_kernel(const T* __restrict
         const int ph = oh >> 1, pw = ow >> 1;
         if (ph >= H1 || pw >= W1) continue;
         const int64_t pix = ((int64_t)b * H1 + ph) * W1 + pw;
-        const uint64_t code = code1[pix];
+        uint32_t fields[4];                                                       // code1 format: see conv1_fwd_kernel
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) fields[g4] = code1[code1_field((uint32_t)(b * H1 + ph), (W1 + 3) >> 2, pw, g4)];
         const uint32_t pos_here = (uint32_t)((oh & 1) * 2 + (ow & 1));
         const T* g16 = dp1 + pix * 16;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
-          const uint32_t field = (uint32_t)(code >> (16 * (c >> 2))) & 0xffffu;   // code1 format: see conv1_fwd_kernel
-          const bool hit = ((field >> (8 + (c & 3))) & 1u) && ((field >> (2 * (c & 3))) & 3u) == pos_here;
+          const uint32_t nib = fields[c >> 2] >> (4 * (c & 3));
+          const bool hit = ((nib >> 2) & 1u) && (nib & 3u) == pos_here;
           acc += hit ? ws[c * 4 + kh * 2 + kw] * to_f32(g16[c]) : 0.f;
         }
       }
@@ -427,7 +444,10 @@ inline void launch_slab_sum(const float* slabs, int nslabs, int width, float* sc
 // =====================================================================================================================
 // conv2 block.  Tile = ROWS (4) conv rows x COLS (128) conv columns of one image per 256-thread workgroup; wave w owns
 // columns [32w, 32w+32).  Activations/gradients around it are channels-last:
-//   p1, dp1 (B,H1,W1,16)   p2, dp2 (B,H2,W2,32)   code2 (B,H2,W2,32) uint8 (0..3 argmax position, 4 = ReLU-dead)
+//   p1, dp1 (B,H1,W1,16)   p2, dp2 (B,H2,W2,32)   code2 (B,H2,W2,16) uint8: one byte per channel PAIR (2j, 2j+1) =
+//   8 * (c_even + 5 * c_odd) with c = 0..3 argmax position, 4 = ReLU-dead -- i.e. the byte offset of the pair's entry
+//   in the backward kernels' 8-byte selector tables (Code2Tables), so that rebuilding the sparse full-resolution
+//   gradient costs one v_bfe, two table reads and four v_perm per two channels and four positions
 // Weights are consumed from a pre-packed image (gdm_simnn_conv2_pack, rebuilt after every optimizer step):
 //   forward  image Wf[32][KPF]: k = tap*16 + ci                       (zero padded to the MFMA k granularity)
 //   backward image Wb[16][KPB]: k = tap'*32 + o with tap' = 8 - tap   (the flipped kernel of the data gradient)
@@ -603,7 +623,7 @@ __device__ __forceinline__ void conv2_fwd_tile(const T* __restrict__ in_s, const
   // ---- epilogue, all in-lane: first maximum of the window in scan order (as aten::max_pool2d_with_indices), ReLU,
   //      code = window position, or 4 when the pooled value is not positive (ReLU passes no gradient)
   float best[8];
-  uint64_t codes = 0;
+  uint32_t codes = 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -615,7 +635,9 @@ __device__ __forceinline__ void conv2_fwd_tile(const T* __restrict__ in_s, const
       pos = v1 == m ? 1u : pos;
       pos = v0 == m ? 0u : pos;
       best[4 * i + r] = fmaxf(m, 0.f);
-      codes |= (uint64_t)(m > 0.f ? pos : 4u) << (8 * (4 * i + r));
+      const uint32_t c = m > 0.f ? pos : 4u;
+      // pair byte 8 * (c_even + 5 * c_odd) of channels 2j, 2j+1 (j = (4i + r) / 2) = byte j of the word (<= 192)
+      codes += ((r & 1) ? c * 40u : c * 8u) << (8 * ((4 * i + r) >> 1));
     }
   const int ph = (ROWS / 2) * rq + rp, pw = (c0 >> 1) + pcol;
   const bool ok = ph < H2 && pw < W2;
@@ -629,7 +651,7 @@ __device__ __forceinline__ void conv2_fwd_tile(const T* __restrict__ in_s, const
     buf_store16(p2r, ok ? gi * 4u : BUF_OOB, (f32x4){best[0], best[1], best[2], best[3]});
     buf_store16(p2r, ok ? gi * 4u + 16u : BUF_OOB, (f32x4){best[4], best[5], best[6], best[7]});
   }
-  buf_store8<GDM_ACT_STORE_AUX>(code2r, ok ? gi : BUF_OOB, codes);
+  __builtin_amdgcn_raw_buffer_store_b32(codes, code2r, ok ? gi >> 1 : BUF_OOB, 0, GDM_ACT_STORE_AUX);
 }
 
 // Persistent over tiles; the weight image and the biases are fetched once per workgroup; input bands are prefetched
@@ -652,7 +674,7 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
   const int B = n_tiles / (n_ctiles * nrq);
   const rsrc_t p1r = make_rsrc(p1, (uint32_t)B * H1 * W1 * 16 * sizeof(T));
   const rsrc_t p2r = make_rsrc(p2, (uint32_t)B * H2 * W2 * 32 * sizeof(T));
-  const rsrc_t code2r = make_rsrc(code2, (uint32_t)B * H2 * W2 * 32);
+  const rsrc_t code2r = make_rsrc(code2, (uint32_t)B * H2 * W2 * 16);
   auto issue = [&](P1Stage<T, ROWS + 2>& st, int u) {
     u = min(u, n_tiles - 1);
     const int ct = u % n_ctiles, rq = (u / n_ctiles) % nrq, b = u / (n_ctiles * nrq);
@@ -713,6 +735,38 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
 // FUSE: instead of (or besides) writing dp1, route it through conv1's ReLU/pool code and contract it with the input
 // window held in LDS:  dW1[c][kh][kw] += live * dp1[c] * x[2ih+dy-1+kh][2iw+dx-1+kw],  db1[c] += live * dp1[c];
 // the workgroup's 80 partial sums go to one slab (summed in fixed order by slab_sum_kernel).
+// Selector tables for code2's pair bytes (bf16 kernels): entry e = c_even + 5 * c_odd at byte offset 8e of
+//   table A: {selector for position 0, position 1}   table B: {position 2, position 3}   table C: {live channels, -}
+// A selector moves the even channel's bf16 gradient (bytes 0,1 of the packed pair) and/or the odd channel's (bytes 2,3)
+// to its place when that channel's argmax is the position, and writes zero (0x0c) otherwise.  25 entries x 8 B: two
+// entries share a 16-byte LDS slot only 16 entries apart -> a table read is at most 2-way conflicted.
+constexpr int C2T_BYTES = 3 * 256;
+__device__ __forceinline__ void code2_tables_init(uint32_t* tab) {
+  const int e = threadIdx.x;
+  if (e < 25) {
+    const uint32_t c0 = e % 5, c1 = e / 5;
+    auto sel = [&](uint32_t pos) { return (c0 == pos ? 0x0100u : 0x0c0cu) | (c1 == pos ? 0x03020000u : 0x0c0c0000u); };
+    tab[2 * e] = sel(0); tab[2 * e + 1] = sel(1);
+    tab[64 + 2 * e] = sel(2); tab[64 + 2 * e + 1] = sel(3);
+    tab[128 + 2 * e] = (c0 != 4 ? 0x0100u : 0x0c0cu) | (c1 != 4 ? 0x03020000u : 0x0c0c0000u);
+    tab[128 + 2 * e + 1] = 0x0c0c0c0cu;
+  }
+}
+// the four position-masked copies of one packed channel pair gw whose pair byte is `off8` (already a table offset)
+__device__ __forceinline__ void code2_expand_pair(const unsigned char* tab, uint32_t off8, uint32_t gw, uint32_t (&out)[4]) {
+  const u32x2 sa = *(const u32x2*)(tab + off8), sb = *(const u32x2*)(tab + 256 + off8);
+  out[0] = __builtin_amdgcn_perm(0u, gw, sa[0]);
+  out[1] = __builtin_amdgcn_perm(0u, gw, sa[1]);
+  out[2] = __builtin_amdgcn_perm(0u, gw, sb[0]);
+  out[3] = __builtin_amdgcn_perm(0u, gw, sb[1]);
+}
+// fp32 kernels: the two channel codes of a pair byte
+__device__ __forceinline__ void code2_pair_codes(uint32_t byte8, uint32_t& c_even, uint32_t& c_odd) {
+  const uint32_t n = byte8 >> 3;            // 0..24
+  c_odd = (n * 13u) >> 6;                   // n / 5
+  c_even = n - 5u * c_odd;
+}
+
 constexpr int BD_COLS = 64;
 constexpr int BD_RING = 8;                     // conv rows in the LDS ring
 constexpr int BD_WPX = BD_COLS + 4;            // stored columns: band column cl = -1 .. 66 lives at index cl + 1
@@ -724,20 +778,33 @@ constexpr int BD_DCIT = (BD_ITEMS * 4 + 255) / 256;
 #endif
 constexpr int BD_XW = GDM_BD_XW;               // x-window row stride in LDS (>= BD_XCOLS = 136, multiple of 4)
 constexpr int BD_XCOLS = 2 * BD_COLS + 8;      // x-window columns 2c0-4 .. 2c0+131 (16-byte aligned start)
+// bf16 FUSE ("MF") epilogue: conv1's weight gradient is one more MFMA product (see conv2_bwd_data_kernel).  The input
+// window lives in LDS as four bf16 planes [hi|lo part][kw] of XROWS rows: plane(kw)[row][m] = x[row][m + 3 + kw], so
+// that the 8 window values a lane needs for its 4 pixels x 2 pooling columns are ONE aligned 16-byte read.  Row stride
+// 288 B and plane stride = 64 (mod 256) B put the 16 (plane, kh, lane group) combinations of a read on 16 distinct
+// 16-byte slots of the 256-byte bank row.
+constexpr int XP_ROW = 144;                     // bf16 elements per plane row (128 used)
+constexpr int XP_PLANE = XROWS * XP_ROW + 16;   // elements (2624 B)
+constexpr int XP_ONES = 8 * XP_ROW;             // a block of 1.0: the B operand column that sums the bias gradient
+constexpr int XP_ELEMS = 4 * XP_PLANE + XP_ONES;
 template <typename T> struct BD {
   static constexpr int DC_ELEMS = BD_RING * BD_WPX * C2<T>::S32;
+  static constexpr size_t TAB = sizeof(T) == 2 ? C2T_BYTES : 0;      // code2 selector tables (bf16)
   static constexpr size_t lds_bytes(bool fuse) {
-    return (size_t)(DC_ELEMS + C2<T>::WB_ELEMS) * sizeof(T) + (fuse ? (size_t)(XROWS * BD_XW + 4 * 80) * 4 : 0);
+    if (!fuse) return (size_t)(DC_ELEMS + C2<T>::WB_ELEMS) * sizeof(T) + TAB;
+    const size_t xbytes = sizeof(T) == 2 ? (size_t)XP_ELEMS * 2 + 64 : (size_t)(XROWS * BD_XW) * 4;
+    return (size_t)(DC_ELEMS + C2<T>::WB_ELEMS) * sizeof(T) + TAB + xbytes + (size_t)(4 * 80) * 4;
   }
 };
 
 // Everything a workgroup fetches from HBM for one step, held in registers between "issue" and "consume".
 template <typename T, bool FUSE, bool XVEC> struct BdStepRegs {
   static constexpr int XIT = FUSE ? (XVEC ? (XROWS * (BD_XCOLS / 4) + 255) / 256 : (XROWS * BD_XCOLS + 255) / 256) : 1;
+  static constexpr bool MF = FUSE && sizeof(T) == 2;
   f32x4 g[BD_DCIT][sizeof(T) == 2 ? 1 : 2];
-  uint64_t cd[BD_DCIT];
+  uint32_t cd[BD_DCIT];                       // four pair bytes = the item's 8 channels
   f32x4 xv4[XVEC ? XIT : 1];
-  float xv[XVEC ? 1 : XIT];
+  float xv[XVEC ? (MF ? XIT : 1) : XIT];     // XVEC && MF: the window value left of each vector (column bc - 1)
   uint64_t codes[FUSE ? 4 : 1];
 };
 
@@ -760,14 +827,15 @@ __device__ __forceinline__ void bd_issue(BdStepRegs<T, FUSE, XVEC>& rg, const Bd
                                          int rq, const BdRsrc& rs, int H1, int W1, int H2, int W2,
                                          const float* __restrict__ x0, const float* __restrict__ x1, int bsplit, int H,
                                          int W) {
-  const int t = threadIdx.x, lr = t & 15, wv = t >> 6;
+  constexpr bool MF = FUSE && sizeof(T) == 2;
+  const int t = threadIdx.x, lr = t & 15, lg = (t >> 4) & 3, wv = t >> 6;
   const int pr0 = 2 * rq + 1, pc0 = (c0 >> 1) - 1;
   const uint32_t base = (uint32_t)b * H2 * W2 * 32 + (uint32_t)(pr0 * W2 + pc0) * 32;   // may wrap: only used when valid
 #pragma unroll
   for (int k = 0; k < BD_DCIT; ++k) {
     const bool ok = (unsigned)(pr0 + ln.dc_prow[k]) < (unsigned)H2 && (unsigned)(pc0 + ln.dc_pcol[k]) < (unsigned)W2;
     const uint32_t gi = base + ln.dc_off[k];
-    rg.cd[k] = buf_load8(rs.code2, ok ? gi : BUF_OOB);
+    rg.cd[k] = __builtin_bit_cast(uint32_t, buf_load4(rs.code2, ok ? gi >> 1 : BUF_OOB));
     rg.g[k][0] = buf_load16(rs.dp2, ok ? gi * (uint32_t)sizeof(T) : BUF_OOB);
     if constexpr (sizeof(T) == 4) rg.g[k][1] = buf_load16(rs.dp2, ok ? gi * 4u + 16u : BUF_OOB);
   }
@@ -779,27 +847,51 @@ __device__ __forceinline__ void bd_issue(BdStepRegs<T, FUSE, XVEC>& rg, const Bd
     const uint32_t xbase = (uint32_t)(xr0 * W + xc0) * 4u;
 #pragma unroll
     for (int k = 0; k < BdLane<FUSE, XVEC>::XIT; ++k) {
-      // XVEC: W % 4 == 0, a 4-column vector is inside or outside the image as a whole
-      const bool ok = (unsigned)(xr0 + ln.x_br[k]) < (unsigned)H && (unsigned)(xc0 + ln.x_bc[k]) < (unsigned)W;
-      const uint32_t off = ok ? xbase + ln.x_off[k] : BUF_OOB;
-      if constexpr (XVEC) rg.xv4[k] = buf_load16<GDM_IN_LOAD_AUX>(xr_, off);
-      else rg.xv[k] = buf_load4<GDM_IN_LOAD_AUX>(xr_, off);
+      // XVEC: W % 4 == 0, a 4-column vector is inside or outside the image as a whole.  Row and column validity are
+      // merged ARITHMETICALLY (OR of the out-of-range bit): with `row_ok && col_ok` shared by two loads the compiler
+      // turned the row test into a branch around them and put s_waitcnt vmcnt(0) in front of the second version of each
+      // load -- every step then waited for everything in flight, the look-ahead was gone.
+      const uint32_t rbad = (unsigned)(xr0 + ln.x_br[k]) < (unsigned)H ? 0u : BUF_OOB;
+      const uint32_t off = ((unsigned)(xc0 + ln.x_bc[k]) < (unsigned)W ? xbase + ln.x_off[k] : BUF_OOB) | rbad;
+      if constexpr (XVEC) {
+        rg.xv4[k] = buf_load16<GDM_IN_LOAD_AUX>(xr_, off);
+        if constexpr (MF) {
+          // the kw = 0 plane is the kw = 1 plane shifted by one column: each vector also needs its left neighbour
+          const uint32_t offm = ((unsigned)(xc0 + ln.x_bc[k] - 1) < (unsigned)W ? xbase + ln.x_off[k] - 4u : BUF_OOB) | rbad;
+          rg.xv[k] = buf_load4<GDM_IN_LOAD_AUX>(xr_, offm);
+        }
+      } else {
+        rg.xv[k] = buf_load4<GDM_IN_LOAD_AUX>(xr_, off);
+      }
     }
-    // conv1 codes of this wave's 16 columns, rows 4rq .. 4rq+3
-    const int iw = c0 + 16 * wv + lr;
-    const uint32_t cbase = (uint32_t)((b * H1 + ROWS * rq) * W1 + iw) * 8u;
+    const int Q1 = (W1 + 3) >> 2;
+    if constexpr (MF) {
+      // lane (channel lr, pixel quad lg of this wave's 16 columns): the four pixels' fields of channel group lr / 4
+      const int quad = (c0 >> 2) + 4 * wv + lg;
+      const uint32_t cbase = (((uint32_t)(b * H1 + ROWS * rq) * Q1 + quad) * 4u + (uint32_t)(lr >> 2)) * 8u;
 #pragma unroll
-    for (int ir = 0; ir < 4; ++ir) {
-      const bool ok = (unsigned)(ROWS * rq + ir) < (unsigned)H1 && iw < W1;
-      rg.codes[ir] = buf_load8<GDM_IN_LOAD_AUX>(rs.code1, ok ? cbase + (uint32_t)(ir * W1) * 8u : BUF_OOB);
+      for (int ir = 0; ir < 4; ++ir) {
+        const bool ok = (unsigned)(ROWS * rq + ir) < (unsigned)H1 && quad < Q1;
+        rg.codes[ir] = buf_load8<GDM_IN_LOAD_AUX>(rs.code1, ok ? cbase + (uint32_t)(ir * Q1) * 32u : BUF_OOB);
+      }
+    } else {
+      // lane (pixel lr, channel group lg): one 16-bit field per row, rows 4rq .. 4rq+3
+      const int iw = c0 + 16 * wv + lr;
+#pragma unroll
+      for (int ir = 0; ir < 4; ++ir) {
+        const bool ok = (unsigned)(ROWS * rq + ir) < (unsigned)H1 && iw < W1;
+        const uint32_t fi = code1_field((uint32_t)(b * H1 + ROWS * rq + ir), Q1, iw, lg) * 2u;
+        rg.codes[ir] = (uint64_t)__builtin_amdgcn_raw_buffer_load_b16(rs.code1, ok ? fi : BUF_OOB, 0, GDM_IN_LOAD_AUX);
+      }
     }
   }
 }
 
 // Registers of step rq -> ring rows 4rq+2 .. 4rq+5.  Lane = (pooled pixel, 8-channel group): four 16-byte records.
+// (OOB items loaded zeros: pair byte 0 = "both channels at position 0" of a zero gradient -> zeros everywhere.)
 template <typename T, bool FUSE, bool XVEC>
 __device__ __forceinline__ void bd_expand(const BdStepRegs<T, FUSE, XVEC>& rg, const BdLane<FUSE, XVEC>& ln, int rq,
-                                          T* __restrict__ dc_s) {
+                                          T* __restrict__ dc_s, const unsigned char* __restrict__ tab) {
   constexpr int S32 = C2<T>::S32;
   const int og = threadIdx.x & 3;
 #pragma unroll
@@ -807,84 +899,108 @@ __device__ __forceinline__ void bd_expand(const BdStepRegs<T, FUSE, XVEC>& rg, c
     const int prow = ln.dc_prow[k], pcol = ln.dc_pcol[k];
     if (prow > 1) continue;
     const int slot = (ROWS * rq + 2 + 2 * prow) & (BD_RING - 1);       // even: slot + 1 never wraps
-    const uint64_t cd = rg.cd[k];
+    const uint32_t cd = rg.cd[k];
     if constexpr (sizeof(T) == 2) {
-      // Packed 16-bit arithmetic on (code, gradient) pairs, two channels per VGPR: the gradient words stay bf16 and
-      // the selection is an AND with the 0xffff/0 lane mask  ((code ^ pos) - 1) >> 15.
-      const uint32_t clo = (uint32_t)cd, chi = (uint32_t)(cd >> 32);
-      uint32_t c16[4], gw[4];
-      c16[0] = __builtin_amdgcn_perm(0u, clo, 0x0c010c00u);     // {code0, code1} in the two 16-bit lanes
-      c16[1] = __builtin_amdgcn_perm(0u, clo, 0x0c030c02u);
-      c16[2] = __builtin_amdgcn_perm(0u, chi, 0x0c010c00u);
-      c16[3] = __builtin_amdgcn_perm(0u, chi, 0x0c030c02u);
       const u32x4 gv = __builtin_bit_cast(u32x4, rg.g[k][0]);
+      uint32_t ex[4][4];                                                  // [channel pair][position]
 #pragma unroll
-      for (int w = 0; w < 4; ++w) gw[w] = gv[w];
+      for (int w = 0; w < 4; ++w) code2_expand_pair(tab, (cd >> (8 * w)) & 0xffu, gv[w], ex[w]);
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
         const int sc = 2 * pcol + dx;                                         // stored column
         const int piece = og ^ ((sc >> 1) & 2);                               // swizzled 16-byte slot of the record
         T* dst = dc_s + (slot * BD_WPX + sc) * S32 + 8 * piece;
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy) {
-          const uint32_t pos = 2 * dy + dx;
-          u32x4 v;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            const s16x2 tq = __builtin_bit_cast(s16x2, c16[w] ^ (0x00010001u * pos));
-            const s16x2 m = (tq - (s16x2){1, 1}) >> 15;
-            v[w] = gw[w] & __builtin_bit_cast(uint32_t, m);
-          }
-          *(u32x4*)(dst + dy * BD_WPX * S32) = v;
-        }
+        for (int dy = 0; dy < 2; ++dy)
+          *(u32x4*)(dst + dy * BD_WPX * S32) = (u32x4){ex[0][2 * dy + dx], ex[1][2 * dy + dx], ex[2][2 * dy + dx],
+                                                       ex[3][2 * dy + dx]};
       }
     } else {
       float g[8];
+      uint32_t c[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { g[e] = rg.g[k][0][e]; g[4 + e] = rg.g[k][1][e]; }
+      for (int e = 0; e < 4; ++e) {
+        g[e] = rg.g[k][0][e]; g[4 + e] = rg.g[k][1][e];
+        code2_pair_codes((cd >> (8 * e)) & 0xffu, c[2 * e], c[2 * e + 1]);
+      }
 #pragma unroll
       for (int pos = 0; pos < 4; ++pos) {
         T* dst = dc_s + ((slot + (pos >> 1)) * BD_WPX + 2 * pcol + (pos & 1)) * S32 + 8 * og;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dst[e] = (int)((cd >> (8 * e)) & 0xff) == pos ? g[e] : 0.f;
+        for (int e = 0; e < 8; ++e) dst[e] = (int)c[e] == pos ? g[e] : 0.f;
       }
     }
   }
 }
 
-template <typename T, bool FUSE, bool XVEC>
+// bf16 FUSE ("MF"): the data-gradient MFMA is issued with its operands SWAPPED (A = gradient fragments: rows = pixels,
+// B = weights: columns = input channels), so a lane of the result holds ONE channel (lr) and FOUR neighbouring pixels
+// (4 lg + r) of each of the step's four rows.  That is the A-operand layout of one more MFMA product,
+//     S[c][n] += sum_k A[c][k] * X[k][n],      k = (pixel 4lg + r, pooling column dx)  for a fixed (row ir, pooling row dy)
+//     A[c][k] = dp1[c][pixel] if channel c of that pixel is live and its argmax is (dy, dx), else 0
+//     X[k][n] = x[2 ih + dy - 1 + kh][2 iw + dx - 1 + kw]  for n = tap (kh, kw) -- 8 CONSECUTIVE window values,
+// i.e. conv1's weight gradient as the weight gradient of the full-resolution convolution (K = full-resolution pixels,
+// one non-zero per pooling window): 8 MFMAs per wave and step.  A is built from the accumulators with one cvt_pk, one
+// 8-byte LDS table read (argmax code -> two v_perm selectors) and two v_perm per value; X is one aligned 16-byte read
+// from the bf16 planes (columns 0-3 of the result: high parts of x, 4-7: low parts -- x stays exact to 2^-17 --,
+// column 8: a block of ones = the bias gradient).  The round-1/2 epilogue (position-dependent 2x2 gathers from an fp32
+// window + 20 FMAs per value: 58 of the kernel's 117 us, 37 % of its LDS cycles bank conflicts) is kept for fp32 only.
+// DP1: the data gradient itself is written out (always without FUSE; with FUSE only for the module's input-gradient
+// path -- the training step never needs it, and as a run-time test the 16 stores stayed in the step body).
+template <typename T, bool FUSE, bool XVEC, bool DP1>
 __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict__ dp2,
                                                              const uint8_t* __restrict__ code2,
                                                              const T* __restrict__ wb, int B, int H1, int W1, int H2,
                                                              int W2, int n_ctiles, int nseg, int seg_len,
                                                              int n_strips, T* __restrict__ dp1,
-                                                             const uint64_t* __restrict__ code1,
+                                                             const uint16_t* __restrict__ code1,
                                                              const float* __restrict__ x0,
                                                              const float* __restrict__ x1, int bsplit, int H, int W,
                                                              float* __restrict__ slabs) {
   constexpr int S32 = C2<T>::S32, KP = C2<T>::KPB, XW = BD_XW;
+  constexpr bool MF = FUSE && sizeof(T) == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   T* dc_s = (T*)dyn_smem;
   T* w_s = dc_s + BD<T>::DC_ELEMS;
-  float* x_s = (float*)(w_s + C2<T>::WB_ELEMS);          // FUSE only: [XROWS][XW]
-  float* red = x_s + XROWS * XW;                          // FUSE only: [4][80]
+  unsigned char* tab_s = (unsigned char*)(w_s + C2<T>::WB_ELEMS);     // bf16: code2 selector tables
+  float* x_s = (float*)(tab_s + BD<T>::TAB);              // FUSE, fp32: [XROWS][XW]
+  __bf16* xp_s = (__bf16*)(tab_s + BD<T>::TAB);           // MF: four planes + ones block, then the selector table
+  uint32_t* tbl_s = (uint32_t*)(xp_s + XP_ELEMS);         // MF: 8 x {selector for dy = 0, selector for dy = 1}
+  float* red = MF ? (float*)(tbl_s + 16) : x_s + XROWS * XW;   // FUSE: [4][80]
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
   const int nrq = (H1 + ROWS - 1) / ROWS, G = gridDim.x;
 
-  float a1[4][4], bs[4];
+  float a1[MF ? 1 : 4][4], bs[4];
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f};                         // MF: S[c = 4lg + r][n = lr]
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     bs[r] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a1[r][q] = 0.f;
+    for (int q = 0; q < 4; ++q) a1[MF ? 0 : r][q] = 0.f;
   }
   STAMP_DECL;
   BdRsrc rs;
   rs.dp2 = make_rsrc(dp2, (uint32_t)B * H2 * W2 * 32 * sizeof(T));
-  rs.code2 = make_rsrc(code2, (uint32_t)B * H2 * W2 * 32);
-  rs.dp1 = make_rsrc(dp1, dp1 ? (uint32_t)B * H1 * W1 * 16 * sizeof(T) : 0u);
-  rs.code1 = make_rsrc(code1, FUSE ? (uint32_t)B * H1 * W1 * 8 : 0u);
+  rs.code2 = make_rsrc(code2, (uint32_t)B * H2 * W2 * 16);
+  rs.dp1 = make_rsrc(dp1, DP1 ? (uint32_t)B * H1 * W1 * 16 * sizeof(T) : 0u);
+  rs.code1 = make_rsrc(code1, FUSE ? (uint32_t)B * H1 * ((W1 + 3) >> 2) * 32 : 0u);
   copy_to_lds(w_s, wb, C2<T>::WB_ELEMS);
+  if constexpr (sizeof(T) == 2) code2_tables_init((uint32_t*)tab_s);
+  if constexpr (MF) {
+    // argmax code (bits 1:0 position, bit 2 live) -> v_perm selectors that place the bf16 gradient (bytes 0,1 of the
+    // source) in the low (dx = 0) or high (dx = 1) half of the A dword of pooling row dy, or nowhere (0x0c = 0x00)
+    if (t < 8) {
+      const uint32_t none = 0x0c0c0c0cu, lo = 0x0c0c0100u, hi = 0x01000c0cu;
+      const bool live = t >= 4;
+      const int pos = t & 3;
+      tbl_s[2 * t] = (live && (pos >> 1) == 0) ? ((pos & 1) ? hi : lo) : none;
+      tbl_s[2 * t + 1] = (live && (pos >> 1) == 1) ? ((pos & 1) ? hi : lo) : none;
+    }
+    for (int i = t; i < XP_ONES / 2; i += 256) ((uint32_t*)(xp_s + 4 * XP_PLANE))[i] = 0x3f803f80u;   // bf16 1.0 pairs
+    // plane cells no step ever writes (row padding, columns the window does not reach) must hold finite values:
+    // they are read by lanes whose result columns are discarded
+    for (int i = t; i < 4 * XP_PLANE / 2; i += 256) ((uint32_t*)xp_s)[i] = 0u;
+  }
 
   BdLane<FUSE, XVEC> ln;
 #pragma unroll
@@ -915,11 +1031,35 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
     rq_first = sg * seg_len;
     rq_end = min(rq_first + seg_len, nrq);
   };
-  BdStepRegs<T, FUSE, XVEC> rg;
-  int s = blockIdx.x, b, c0, rq_first, rq_end;              // host guarantees gridDim.x <= n_strips
-  place(s, b, c0, rq_first, rq_end);
-  int rq = rq_first - 1;
-  bd_issue<T, FUSE, XVEC>(rg, ln, b, c0, rq, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
+  // Step positions.  The loads of a step are issued TWO steps ahead into one of two register sets: with one step of
+  // look-ahead a step could not be shorter than one HBM round trip under load (~2 us) -- halving the step's VALU work
+  // (round 3: 418 -> 270 instructions per wave) did not move the kernel by a microsecond until the look-ahead doubled.
+  struct Pos { int s, b, c0, rq, rq_first, rq_end; };
+  auto advance = [&](const Pos& q) {
+    Pos n = q;
+    if (q.s >= n_strips) return n;                          // past the end: keep re-reading the last rows
+    n.rq = q.rq + 1;
+    if (n.rq == q.rq_end) {
+      n.s = q.s + G;
+      if (n.s < n_strips) {
+        place(n.s, n.b, n.c0, n.rq_first, n.rq_end);
+        n.rq = n.rq_first - 1;
+      } else {
+        n.rq = q.rq;                                        // nothing left: its loads re-read cache-hot rows
+      }
+    }
+    return n;
+  };
+  // (fp32: one register set, one step of look-ahead -- a second set does not fit 256 VGPRs beside the 72 weight registers)
+  constexpr bool AHEAD2 = sizeof(T) == 2;
+  BdStepRegs<T, FUSE, XVEC> rg_a, rg_b;
+  Pos p0, p1;
+  p0.s = blockIdx.x;                                        // host guarantees gridDim.x <= n_strips
+  place(p0.s, p0.b, p0.c0, p0.rq_first, p0.rq_end);
+  p0.rq = p0.rq_first - 1;
+  p1 = advance(p0);
+  bd_issue<T, FUSE, XVEC>(rg_a, ln, p0.b, p0.c0, p0.rq, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
+  if constexpr (AHEAD2) bd_issue<T, FUSE, XVEC>(rg_b, ln, p1.b, p1.c0, p1.rq, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
   __syncthreads();                                          // weight image complete
 
   // Wave w computes the 4 output rows of column tile w (16 columns).  A dc2 row fragment (one per tap column aw) feeds
@@ -941,21 +1081,74 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
       cb[aw] = sc * S32 + 8 * (lg ^ ((sc >> 1) & 2));
     }
   }
+  // MF: per-lane constants of the epilogue
+  //   xb_off: element offset of this lane's X fragment for (ir, dy) = (0, 0); result column n = lr: n < 4 high plane of
+  //           tap (kh, kw) = (n >> 1, n & 1), 4..7 the low plane, >= 8 the block of ones (only column 8 is used)
+  //   sh0/sh1: rotation that brings the lane's channel nibble of pixel r (even / odd: low / high half word) to bits 5:3
+  const int xb_off = lr < 8 ? (2 * (lr >> 2) + (lr & 1)) * XP_PLANE + ((lr >> 1) & 1) * XP_ROW + 32 * wv + 8 * lg
+                            : 4 * XP_PLANE;
+  const uint32_t sh0 = 29u + 4u * (lr & 3), sh1 = sh0 + 16u;
   STAMP(6);
-  while (s < n_strips) {
+  auto step = [&](BdStepRegs<T, FUSE, XVEC>& rg, const Pos& cur, const Pos& nxt) {
+    const int b = cur.b, c0 = cur.c0, rq = cur.rq, rq_first = cur.rq_first;
     // ---- consume the prefetched registers into the LDS images of this step
 #ifdef GDM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(3);
 #endif
-    bd_expand<T, FUSE, XVEC>(rg, ln, rq, dc_s);
+    bd_expand<T, FUSE, XVEC>(rg, ln, rq, dc_s, tab_s);
     uint64_t codes[FUSE ? 4 : 1];
     if constexpr (FUSE) {
+      if constexpr (MF) {
+        // fp32 window values -> bf16 high / low parts in the two column-shifted planes
+        auto split = [](float v0, float v1, uint32_t& hi, uint32_t& lo) {
+          const bf16x2 h = {(__bf16)v0, (__bf16)v1};
+          hi = __builtin_bit_cast(uint32_t, h);
+          const float r0 = v0 - __builtin_bit_cast(float, hi << 16), r1 = v1 - __builtin_bit_cast(float, hi & 0xffff0000u);
+          const bf16x2 lw = {(__bf16)r0, (__bf16)r1};
+          lo = __builtin_bit_cast(uint32_t, lw);
+        };
 #pragma unroll
-      for (int k = 0; k < BdLane<FUSE, XVEC>::XIT; ++k) {
-        if (ln.x_br[k] < XROWS) {
-          if constexpr (XVEC) *(f32x4*)&x_s[ln.x_br[k] * XW + ln.x_bc[k]] = rg.xv4[k];
-          else x_s[ln.x_br[k] * XW + ln.x_bc[k]] = rg.xv[k];
+        for (int k = 0; k < BdLane<FUSE, XVEC>::XIT; ++k) {
+          if constexpr (XVEC) {
+            // vector = window columns bc .. bc+3 -> plane kw=1 cells m = bc-4 .. bc-1; with the left neighbour in
+            // front (bc-1 .. bc+2) the same cells of plane kw=0
+            if (ln.x_br[k] < XROWS && ln.x_bc[k] >= 4) {
+              const f32x4 v = rg.xv4[k];
+              const float vm = rg.xv[k];
+              __bf16* cell = xp_s + ln.x_br[k] * XP_ROW + ln.x_bc[k] - 4;
+              uint32_t h00, h01, l00, l01, h10, h11, l10, l11;
+              split(vm, v[0], h00, l00);
+              split(v[1], v[2], h01, l01);
+              split(v[0], v[1], h10, l10);
+              split(v[2], v[3], h11, l11);
+              *(u32x2*)(cell) = (u32x2){h00, h01};
+              *(u32x2*)(cell + XP_PLANE) = (u32x2){h10, h11};
+              *(u32x2*)(cell + 2 * XP_PLANE) = (u32x2){l00, l01};
+              *(u32x2*)(cell + 3 * XP_PLANE) = (u32x2){l10, l11};
+            }
+          } else {
+            // one window value: cell m = bc - 3 of plane kw=0 and m = bc - 4 of plane kw=1
+            if (ln.x_br[k] < XROWS && ln.x_bc[k] >= 3) {
+              const float v = rg.xv[k];
+              const __bf16 h = (__bf16)v, lw = (__bf16)(v - (float)h);
+              __bf16* cell = xp_s + ln.x_br[k] * XP_ROW + ln.x_bc[k] - 3;
+              cell[0] = h;
+              cell[2 * XP_PLANE] = lw;
+              if (ln.x_bc[k] >= 4) {
+                cell[XP_PLANE - 1] = h;
+                cell[3 * XP_PLANE - 1] = lw;
+              }
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < BdLane<FUSE, XVEC>::XIT; ++k) {
+          if (ln.x_br[k] < XROWS) {
+            if constexpr (XVEC) *(f32x4*)&x_s[ln.x_br[k] * XW + ln.x_bc[k]] = rg.xv4[k];
+            else x_s[ln.x_br[k] * XW + ln.x_bc[k]] = rg.xv[k];
+          }
         }
       }
 #pragma unroll
@@ -964,19 +1157,9 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
     STAMP(7);
     __syncthreads();
     STAMP(0);
-    // the next step's loads fly during the work below; issued on EVERY step (the very last one re-reads its own,
-    // cache-hot rows), so the step body has no branch around memory operations
-    int sn = s, bn = b, c0n = c0, rqn = rq + 1, rq_first_n = rq_first, rq_end_n = rq_end;
-    if (rqn == rq_end) {
-      sn = s + G;
-      if (sn < n_strips) {
-        place(sn, bn, c0n, rq_first_n, rq_end_n);
-        rqn = rq_first_n - 1;
-      } else {
-        rqn = rq;                                           // nothing left: re-read the current rows
-      }
-    }
-    bd_issue<T, FUSE, XVEC>(rg, ln, bn, c0n, rqn, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
+    // this register set is free again: the loads of the step after next fly during this step and the next one; issued on
+    // EVERY step (past the end they re-read cache-hot rows), so the step body has no branch around memory operations
+    bd_issue<T, FUSE, XVEC>(rg, ln, nxt.b, nxt.c0, nxt.rq, rs, H1, W1, H2, W2, x0, x1, bsplit, H, W);
     STAMP(1);
 
     if (rq >= rq_first) {
@@ -1001,7 +1184,11 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
             const int ir = rr - ah;
             if (ir < 0 || ir >= ROWS) continue;
 #pragma unroll
-            for (int aw = 0; aw < 3; ++aw) acc[ir] = mfma16(afr[3 * ah + aw], bb[rr & 1][aw], acc[ir]);
+            for (int aw = 0; aw < 3; ++aw) {
+              // MF: operands swapped -> result row = pixel 4lg + r, column = input channel lr (same sums, transposed)
+              if constexpr (MF) acc[ir] = mfma16(bb[rr & 1][aw], afr[3 * ah + aw], acc[ir]);
+              else acc[ir] = mfma16(afr[3 * ah + aw], bb[rr & 1][aw], acc[ir]);
+            }
           }
         }
       } else {
@@ -1028,52 +1215,101 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
         }
       }
       STAMP(2);
-      // C layout: col (lr) = pixel, row (4*lg + r) = input channel ci
-      const int iw = c0 + 16 * wv + lr;
-      if (dp1 != nullptr) {
+      if constexpr (MF) {
+        // C layout (swapped): col (lr) = input channel ci, row (4*lg + r) = pixel of the wave's 16 columns
+        if constexpr (DP1) {
 #pragma unroll
-        for (int ir = 0; ir < 4; ++ir) {
-          const int ih = ROWS * rq + ir;
-          const bool ok = ih < H1 && iw < W1;
-          const uint32_t di = (uint32_t)((b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
-          if constexpr (sizeof(T) == 2) {
-            bf16x4 v;
+          for (int ir = 0; ir < 4; ++ir) {
+            const int ih = ROWS * rq + ir;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[ir][r];
-            buf_store8(rs.dp1, ok ? di * 2u : BUF_OOB, __builtin_bit_cast(uint64_t, v));
-          } else {
-            buf_store16(rs.dp1, ok ? di * 4u : BUF_OOB, acc[ir]);
+            for (int r = 0; r < 4; ++r) {
+              const int iw = c0 + 16 * wv + 4 * lg + r;
+              const bool ok = ih < H1 && iw < W1;
+              const uint32_t di = (uint32_t)((b * H1 + ih) * W1 + iw) * 16 + lr;
+              const __bf16 v = (__bf16)acc[ir][r];
+              buf_store2(rs.dp1, ok ? di * 2u : BUF_OOB, (uint32_t)__builtin_bit_cast(unsigned short, v));
+            }
           }
         }
-      }
-      if constexpr (FUSE) {
-        // x window of pixel (row ir, column cl = 16 wv + lr) starts at x_s[2 ir][2 cl + 3]; position (dy, dx) moves it
-        // by dy rows and dx columns: offset = dx + 256 dy = (pos * 129) & 0x101.  The 16 gathers of row ir+1 are issued
-        // before the FMAs of row ir (register double buffer).
-        const float* xcol = x_s + 2 * (16 * wv + lr) + 3;
-        float xw[2][4][4];
-        auto gather = [&](int ir, float (&xo)[4][4]) {
-          const uint32_t pf = (uint32_t)(codes[ir] >> (16 * lg));             // 2-bit positions of channels 4lg..4lg+3
+        const unsigned char* xp_b = (const unsigned char*)xp_s + 2 * xb_off;
+        const unsigned char* tb = (const unsigned char*)tbl_s;
+        u32x2 sel[2][4];
+        auto selectors = [&](int ir, u32x2 (&so)[4]) {
+          const uint32_t clo = (uint32_t)codes[ir], chi = (uint32_t)(codes[ir] >> 32);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const uint32_t pos = (pf >> (2 * r)) & 3u;
-            const float* xp = xcol + 2 * ir * XW + (XW == 256 ? ((pos * 129u) & 0x101u) : (pos & 1u) + XW * (pos >> 1));
-            xo[r][0] = xp[0]; xo[r][1] = xp[1]; xo[r][2] = xp[XW]; xo[r][3] = xp[XW + 1];
+            const uint32_t word = r < 2 ? clo : chi;
+            // rotate right by (nibble offset - 3) mod 32 (the instruction takes the shift modulo 32)
+            const uint32_t idx8 = __builtin_amdgcn_alignbit(word, word, (r & 1) ? sh1 : sh0) & 0x38u;
+            so[r] = *(const u32x2*)(tb + idx8);
           }
         };
-        gather(0, xw[0]);
+        selectors(0, sel[0]);
 #pragma unroll
         for (int ir = 0; ir < 4; ++ir) {
-          if (ir + 1 < 4) gather(ir + 1, xw[(ir + 1) & 1]);
-          const uint32_t lv = (uint32_t)(codes[ir] >> (16 * lg + 8));         // live bits of channels 4lg..4lg+3
+          if (ir + 1 < 4) selectors(ir + 1, sel[(ir + 1) & 1]);      // table reads of the next row fly under this one
+          const bf16x8 xf0 = *(const bf16x8*)(xp_b + (2 * ir) * (XP_ROW * 2));
+          const bf16x8 xf1 = *(const bf16x8*)(xp_b + (2 * ir + 1) * (XP_ROW * 2));
+          u32x4 a0, a1v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const uint32_t live = (uint32_t)((int32_t)(lv << (31 - r)) >> 31);            // 0 or ~0
-            const float av = acc[ir][r];     // (bit_cast straight from a vector element reads element 0)
-            const float g = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, av) & live);
+            const float gv = acc[ir][r];
+            const bf16x2 gp = {(__bf16)gv, (__bf16)gv};
+            const uint32_t gg = __builtin_bit_cast(uint32_t, gp);
+            a0[r] = __builtin_amdgcn_perm(0u, gg, sel[ir & 1][r][0]);
+            a1v[r] = __builtin_amdgcn_perm(0u, gg, sel[ir & 1][r][1]);
+          }
+          s1 = mfma16(__builtin_bit_cast(bf16x8, a0), xf0, s1);
+          s1 = mfma16(__builtin_bit_cast(bf16x8, a1v), xf1, s1);
+        }
+      } else {
+        // C layout: col (lr) = pixel, row (4*lg + r) = input channel ci
+        const int iw = c0 + 16 * wv + lr;
+        if constexpr (DP1) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a1[r][q] = fmaf(g, xw[ir & 1][r][q], a1[r][q]);
-            bs[r] += g;
+          for (int ir = 0; ir < 4; ++ir) {
+            const int ih = ROWS * rq + ir;
+            const bool ok = ih < H1 && iw < W1;
+            const uint32_t di = (uint32_t)((b * H1 + ih) * W1 + iw) * 16 + 4 * lg;
+            if constexpr (sizeof(T) == 2) {
+              bf16x4 v;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = (__bf16)acc[ir][r];
+              buf_store8(rs.dp1, ok ? di * 2u : BUF_OOB, __builtin_bit_cast(uint64_t, v));
+            } else {
+              buf_store16(rs.dp1, ok ? di * 4u : BUF_OOB, acc[ir]);
+            }
+          }
+        }
+        if constexpr (FUSE) {
+          // x window of pixel (row ir, column cl = 16 wv + lr) starts at x_s[2 ir][2 cl + 3]; position (dy, dx) moves it
+          // by dy rows and dx columns: offset = dx + 256 dy = (pos * 129) & 0x101.  The 16 gathers of row ir+1 are issued
+          // before the FMAs of row ir (register double buffer).
+          const float* xcol = x_s + 2 * (16 * wv + lr) + 3;
+          float xw[2][4][4];
+          auto gather = [&](int ir, float (&xo)[4][4]) {
+            const uint32_t pf = (uint32_t)codes[ir];                          // nibbles of channels 4lg..4lg+3
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const uint32_t pos = (pf >> (4 * r)) & 3u;
+              const float* xp = xcol + 2 * ir * XW + (XW == 256 ? ((pos * 129u) & 0x101u) : (pos & 1u) + XW * (pos >> 1));
+              xo[r][0] = xp[0]; xo[r][1] = xp[1]; xo[r][2] = xp[XW]; xo[r][3] = xp[XW + 1];
+            }
+          };
+          gather(0, xw[0]);
+#pragma unroll
+          for (int ir = 0; ir < 4; ++ir) {
+            if (ir + 1 < 4) gather(ir + 1, xw[(ir + 1) & 1]);
+            const uint32_t lv = (uint32_t)codes[ir];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const uint32_t live = (uint32_t)((int32_t)(lv << (29 - 4 * r)) >> 31);        // bit 4r+2 -> 0 or ~0
+              const float av = acc[ir][r];     // (bit_cast straight from a vector element reads element 0)
+              const float g = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, av) & live);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) a1[r][q] = fmaf(g, xw[ir & 1][r][q], a1[r][q]);
+              bs[r] += g;
+            }
           }
         }
       }
@@ -1081,10 +1317,34 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
     }
     __syncthreads();     // every wave is done with this step's LDS images
     STAMP(5);
-    s = sn; b = bn; c0 = c0n; rq = rqn; rq_first = rq_first_n; rq_end = rq_end_n;
+  };
+  while (p0.s < n_strips) {
+    if constexpr (AHEAD2) {
+      const Pos p2 = advance(p1);
+      step(rg_a, p0, p2);
+      const Pos p3 = advance(p2);
+      if (p1.s < n_strips) step(rg_b, p1, p3);
+      p0 = p2;
+      p1 = p3;
+    } else {
+      step(rg_a, p0, p1);
+      p0 = p1;
+      p1 = advance(p1);
+    }
   }
   STAMP_FLUSH;
-  if constexpr (FUSE) {
+  if constexpr (MF) {
+    // S[c = 4lg + r][n = lr]: taps = columns 0..3 (+ their low-part twins 4..7), bias gradient = column 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = s1[r];
+      const float tw = __shfl_down(v, 4, 64);          // lane lr + 4 of the same lane group (lr < 4: no wrap)
+      if (lr < 4) red[wv * 80 + (4 * lg + r) * 4 + lr] = v + tw;
+      if (lr == 8) red[wv * 80 + 64 + 4 * lg + r] = v;
+    }
+    __syncthreads();
+    if (t < 80) slabs[(int64_t)blockIdx.x * 80 + t] = ((red[t] + red[80 + t]) + red[160 + t]) + red[240 + t];
+  } else if constexpr (FUSE) {
     // one reduction per workgroup (not per tile): over the 16 lanes that share a channel group, then over the waves
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1140,6 +1400,8 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
   T* dc_s = (T*)dyn_smem;
   T* p_s = dc_s + BW<T>::DC_ELEMS;
+  const unsigned char* tab_s = (const unsigned char*)(p_s + BW<T>::P_ELEMS);     // bf16: code2 selector tables
+  if constexpr (sizeof(T) == 2) code2_tables_init((uint32_t*)(p_s + BW<T>::P_ELEMS));    // (first barrier: in the loop)
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
   const int nrq = (H1 + ROWS - 1) / ROWS, G = gridDim.x;
   f32x4 acc[2][9];
@@ -1152,7 +1414,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
   for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
 
   const rsrc_t dp2r = make_rsrc(dp2, (uint32_t)B * H2 * W2 * 32 * sizeof(T));
-  const rsrc_t code2r = make_rsrc(code2, (uint32_t)B * H2 * W2 * 32);
+  const rsrc_t code2r = make_rsrc(code2, (uint32_t)B * H2 * W2 * 16);
   const rsrc_t p1r = make_rsrc(p1, (uint32_t)B * H1 * W1 * 16 * sizeof(T));
 
   // ---- per-lane staging constants
@@ -1181,7 +1443,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
 
   struct Regs {
     f32x4 g[sizeof(T) == 2 ? 1 : 2];
-    uint64_t cd;
+    uint32_t cd;
     f32x4 p[(sizeof(T) == 2 ? 1 : 2) * BW<T>::P1IT];
   } rg;
   auto issue = [&](int b, int c0, int rq, bool with_dc) {
@@ -1189,7 +1451,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
       const int pr = 2 * rq + dprow, pc = (c0 >> 1) + dpcol;
       const bool ok = with_dc && pr >= 0 && pr < H2 && pc < W2;
       const uint32_t gi = (uint32_t)b * H2 * W2 * 32 + (uint32_t)(2 * rq * W2 + (c0 >> 1)) * 32 + dc_goff;
-      rg.cd = buf_load8(code2r, ok ? gi : BUF_OOB);
+      rg.cd = __builtin_bit_cast(uint32_t, buf_load4(code2r, ok ? gi >> 1 : BUF_OOB));
       rg.g[0] = buf_load16(dp2r, ok ? gi * (uint32_t)sizeof(T) : BUF_OOB);
       if constexpr (sizeof(T) == 4) rg.g[1] = buf_load16(dp2r, ok ? gi * 4u + 16u : BUF_OOB);
     }
@@ -1241,21 +1503,16 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
 #endif
     // ---- registers -> LDS: dc2 rows of this step, p1 ring rows 4rq+1 .. 4rq+4
     if (rq >= rq_first) {
-      const uint64_t cd = rg.cd;
+      const uint32_t cd = rg.cd;
       if constexpr (sizeof(T) == 2) {
-        const uint32_t clo = (uint32_t)cd, chi = (uint32_t)(cd >> 32);
-        uint32_t c16[4], gw[4];
-        c16[0] = __builtin_amdgcn_perm(0u, clo, 0x0c010c00u);
-        c16[1] = __builtin_amdgcn_perm(0u, clo, 0x0c030c02u);
-        c16[2] = __builtin_amdgcn_perm(0u, chi, 0x0c010c00u);
-        c16[3] = __builtin_amdgcn_perm(0u, chi, 0x0c030c02u);
         const u32x4 gv = __builtin_bit_cast(u32x4, rg.g[0]);
+        uint32_t ex[4][4];                                   // [channel pair][position]
 #pragma unroll
-        for (int w = 0; w < 4; ++w) gw[w] = gv[w];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {                        // bias gradient: channels whose pooled value was live
-          const s16x2 lv = (__builtin_bit_cast(s16x2, c16[w]) - (s16x2){4, 4}) >> 15;
-          const uint32_t g = gw[w] & __builtin_bit_cast(uint32_t, lv);
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t off8 = (cd >> (8 * w)) & 0xffu;
+          code2_expand_pair(tab_s, off8, gv[w], ex[w]);
+          // bias gradient: channels whose pooled value was live
+          const uint32_t g = __builtin_amdgcn_perm(0u, gv[w], *(const uint32_t*)(tab_s + 512 + off8));
           bsum[2 * w] += __builtin_bit_cast(float, g << 16);
           bsum[2 * w + 1] += __builtin_bit_cast(float, g & 0xffff0000u);
         }
@@ -1264,29 +1521,25 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
           const int col = 2 * dpcol + dx;
           T* dst = dc_s + (2 * dprow * COLS + col) * S32 + 8 * BW<T>::dcpiece(og, col);
 #pragma unroll
-          for (int dy = 0; dy < 2; ++dy) {
-            const uint32_t pos = 2 * dy + dx;
-            u32x4 v;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              const s16x2 tq = __builtin_bit_cast(s16x2, c16[w] ^ (0x00010001u * pos));
-              const s16x2 m = (tq - (s16x2){1, 1}) >> 15;
-              v[w] = gw[w] & __builtin_bit_cast(uint32_t, m);
-            }
-            *(u32x4*)(dst + dy * COLS * S32) = v;
-          }
+          for (int dy = 0; dy < 2; ++dy)
+            *(u32x4*)(dst + dy * COLS * S32) = (u32x4){ex[0][2 * dy + dx], ex[1][2 * dy + dx], ex[2][2 * dy + dx],
+                                                       ex[3][2 * dy + dx]};
         }
       } else {
         float g[8];
+        uint32_t c[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { g[e] = rg.g[0][e]; g[4 + e] = rg.g[1][e]; }
+        for (int e = 0; e < 4; ++e) {
+          g[e] = rg.g[0][e]; g[4 + e] = rg.g[1][e];
+          code2_pair_codes((cd >> (8 * e)) & 0xffu, c[2 * e], c[2 * e + 1]);
+        }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bsum[e] += (((cd >> (8 * e)) & 0xff) < 4) ? g[e] : 0.f;
+        for (int e = 0; e < 8; ++e) bsum[e] += c[e] < 4 ? g[e] : 0.f;
 #pragma unroll
         for (int pos = 0; pos < 4; ++pos) {
           T* dst = dc_s + ((2 * dprow + (pos >> 1)) * COLS + 2 * dpcol + (pos & 1)) * S32 + 8 * og;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) dst[e] = (int)((cd >> (8 * e)) & 0xff) == pos ? g[e] : 0.f;
+          for (int e = 0; e < 8; ++e) dst[e] = (int)c[e] == pos ? g[e] : 0.f;
         }
       }
     }
@@ -1493,7 +1746,7 @@ extern "C" int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* 
   static const int cap1 = tuned_cap("GDM_C1_CAP", 1536);               // persistent: 6 workgroups per CU (2048: +0.6 % per iteration)
   if (blocks > cap1) blocks = cap1;
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                                       x, w, bias, B, H, W, H1, W1, (int)n_rows, (T*)p1, code1));
+                                       x, w, bias, B, H, W, H1, W1, (int)n_rows, (T*)p1, (uint16_t*)code1));
   GDM_LAUNCH_OK("gdm_simnn_conv1_fwd");
   return GDM_OK;
 }
@@ -1515,8 +1768,8 @@ extern "C" int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1
   const int H1 = (H + 1) / 2, W1 = (W + 1) / 2;
   const int nslabs = conv1_slabs((int64_t)B * H1 * W1);
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_bwd_weight_kernel<T>, dim3(nslabs), dim3(256), 0, s, (const T*)dp1, code1,
-                                       x, B, H, W, H1, W1, (float*)workspace));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_bwd_weight_kernel<T>, dim3(nslabs), dim3(256), 0, s, (const T*)dp1,
+                                       (const uint16_t*)code1, x, B, H, W, H1, W1, (float*)workspace));
   float* scratch = (float*)workspace + (size_t)nslabs * 80;
   launch_slab_sum<1>((const float*)workspace, nslabs, 80, scratch, dw, db, accumulate, s);
   GDM_LAUNCH_OK("gdm_simnn_conv1_bwd_weight");
@@ -1532,7 +1785,7 @@ extern "C" int gdm_simnn_conv1_bwd_data(const void* dp1, const uint64_t* code1, 
   int64_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_bwd_data_kernel<T>, dim3((unsigned)blocks), dim3(256), 0,
-                                       (hipStream_t)stream, (const T*)dp1, code1, w, B, H, W, H1, W1, dx));
+                                       (hipStream_t)stream, (const T*)dp1, (const uint16_t*)code1, w, B, H, W, H1, W1, dx));
   GDM_LAUNCH_OK("gdm_simnn_conv1_bwd_data");
   return GDM_OK;
 }
@@ -1586,15 +1839,19 @@ int launch_bwd_data(const void* dp2, const uint8_t* code2, const void* pack, int
   const size_t sm = BD<T>::lds_bytes(FUSE);
   // 16-byte x-window loads need rows that start on 16-byte boundaries
   const bool xvec = FUSE && W % 4 == 0 && (((uintptr_t)x0 | (uintptr_t)x1) & 15) == 0;
-#define GDM_BD_LAUNCH(XV)                                                                                              \
-  allow_lds(conv2_bwd_data_kernel<T, FUSE, XV>, sm);                                                                   \
-  hipLaunchKernelGGL((conv2_bwd_data_kernel<T, FUSE, XV>), dim3(pl.blocks), dim3(256), sm, s, (const T*)dp2, code2,    \
+#define GDM_BD_LAUNCH(XV, D1)                                                                                          \
+  allow_lds(conv2_bwd_data_kernel<T, FUSE, XV, D1>, sm);                                                               \
+  hipLaunchKernelGGL((conv2_bwd_data_kernel<T, FUSE, XV, D1>), dim3(pl.blocks), dim3(256), sm, s, (const T*)dp2, code2, \
                      (const T*)pack + C2<T>::WF_ELEMS, B, H1, W1, H2, W2, pl.n_ctiles, pl.nseg, pl.seg_len, pl.n_items, \
-                     (T*)dp1, code1, x0, x1, bsplit, H, W, slabs)
+                     (T*)dp1, (const uint16_t*)code1, x0, x1, bsplit, H, W, slabs)
   if constexpr (FUSE) {
-    if (xvec) { GDM_BD_LAUNCH(true); } else { GDM_BD_LAUNCH(false); }
+    if (dp1 != nullptr) {
+      if (xvec) { GDM_BD_LAUNCH(true, true); } else { GDM_BD_LAUNCH(false, true); }
+    } else {
+      if (xvec) { GDM_BD_LAUNCH(true, false); } else { GDM_BD_LAUNCH(false, false); }
+    }
   } else {
-    GDM_BD_LAUNCH(false);
+    GDM_BD_LAUNCH(false, true);
   }
 #undef GDM_BD_LAUNCH
   GDM_LAUNCH_OK("gdm_simnn_conv2_bwd_data");
@@ -1681,7 +1938,7 @@ extern "C" int gdm_simnn_conv2_bwd_weight(const void* dp2, const uint8_t* code2,
   hipStream_t s = (hipStream_t)stream;
   const size_t red_bytes = (size_t)(4608 + 2048) * sizeof(float);
   if (dtype == GDM_BF16) {
-    size_t sm = (size_t)(BW<__bf16>::DC_ELEMS + BW<__bf16>::P_ELEMS) * 2;
+    size_t sm = (size_t)(BW<__bf16>::DC_ELEMS + BW<__bf16>::P_ELEMS) * 2 + C2T_BYTES;
     if (sm < red_bytes) sm = red_bytes;
     allow_lds(conv2_bwd_weight_kernel<__bf16>, sm);
     hipLaunchKernelGGL(conv2_bwd_weight_kernel<__bf16>, dim3(nblocks), dim3(256), sm, s, (const __bf16*)dp2, code2,

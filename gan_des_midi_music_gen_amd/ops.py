@@ -348,8 +348,15 @@ def cast(x, dt):
 
 
 # ------------------------------------------------------------------------------------------ model 1 conv trunk
+def simnn_code1_width(w1):
+    """Last dimension of the int64 tensor that holds conv1's pool / ReLU codes of a (.., w1)-wide pooled map: 8 bytes
+    per pixel, rows padded to whole quads of four pixels (include/gdm.h, gdm_simnn_conv1_fwd)."""
+    return (w1 + 3) // 4 * 4
+
+
 def simnn_conv1_fwd(x, w, bias, dt, out=None):
-    """out = (p1, code1) preallocated (e.g. halves of a 2B batch buffer) or None."""
+    """out = (p1, code1) preallocated (e.g. halves of a 2B batch buffer) or None; code1: (b, h1, simnn_code1_width(w1))
+    int64 -- an opaque byte image, only ever handed back to the backward entry points."""
     _need_gpu(x, w, bias)
     assert x.dim() == 3 and x.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()
     b, h, wd = x.shape
@@ -357,10 +364,10 @@ def simnn_conv1_fwd(x, w, bias, dt, out=None):
     if out is not None:
         p1, code1 = out
         assert p1.shape == (b, h1, w1, 16) and p1.is_contiguous() and p1.dtype == _TORCH_DT[dt]
-        assert code1.shape == (b, h1, w1) and code1.is_contiguous() and code1.dtype == torch.int64
+        assert code1.shape == (b, h1, simnn_code1_width(w1)) and code1.is_contiguous() and code1.dtype == torch.int64
     else:
         p1 = torch.empty((b, h1, w1, 16), dtype=_TORCH_DT[dt], device=x.device)
-        code1 = torch.empty((b, h1, w1), dtype=torch.int64, device=x.device)
+        code1 = torch.empty((b, h1, simnn_code1_width(w1)), dtype=torch.int64, device=x.device)
     _call("gdm_simnn_conv1_fwd", _p(x), _p(w), _p(bias), b, h, wd, _p(p1), _p(code1), dt, _stream())
     return p1, code1
 
@@ -378,13 +385,13 @@ def simnn_conv2_pack(w, dt, out=None):
 
 
 def simnn_conv2_fwd(p1, pack, bias):
-    """p1 (B,H1,W1,16) -> p2 (B,H2,W2,32) channels-last, code2 (B,H2,W2,32) uint8."""
+    """p1 (B,H1,W1,16) -> p2 (B,H2,W2,32) channels-last, code2 (B,H2,W2,16) uint8 (one byte per channel pair)."""
     _need_gpu(p1, pack, bias)
     assert p1.dim() == 4 and p1.shape[3] == 16 and p1.is_contiguous()
     b, h1, w1, _ = p1.shape
     h2, w2 = h1 // 2, w1 // 2
     p2 = torch.empty((b, h2, w2, 32), dtype=p1.dtype, device=p1.device)
-    code2 = torch.empty((b, h2, w2, 32), dtype=torch.uint8, device=p1.device)
+    code2 = torch.empty((b, h2, w2, 16), dtype=torch.uint8, device=p1.device)
     _call("gdm_simnn_conv2_fwd", _p(p1), _p(pack), _p(bias), b, h1, w1, _p(p2), _p(code2), gdm_dtype(p1), _stream())
     return p2, code2
 
@@ -407,7 +414,8 @@ def simnn_conv2_bwd_fused(dp2, code2, pack, code1, x0, x1=None, out=None, want_d
     assert dp2.is_contiguous() and code2.is_contiguous() and code1.is_contiguous() and x0.is_contiguous()
     b = dp2.shape[0]
     h, wd = x0.shape[1], x0.shape[2]
-    h1, w1 = code1.shape[1], code1.shape[2]
+    h1, w1 = (h + 1) // 2, (wd + 1) // 2
+    assert code1.shape == (b, h1, simnn_code1_width(w1)) and code1.dtype == torch.int64, code1.shape
     bsplit = x0.shape[0]
     if x1 is not None:
         assert x1.is_contiguous() and x1.shape[1:] == x0.shape[1:] and bsplit + x1.shape[0] == b
@@ -451,7 +459,7 @@ def simnn_conv1_bwd_weight(dp1, code1, x, out=None, accumulate=False):
     _need_gpu(dp1, code1, x)
     assert dp1.is_contiguous() and code1.is_contiguous() and x.is_contiguous()
     b, h, wd = x.shape
-    assert dp1.shape[0] == b and code1.shape[0] == b
+    assert dp1.shape[0] == b and code1.shape == (b, (h + 1) // 2, simnn_code1_width((wd + 1) // 2))
     if out is not None:
         dw, db = out
         assert dw.numel() == 64 and db.numel() == 16 and dw.is_contiguous() and db.is_contiguous()
@@ -472,7 +480,8 @@ def simnn_conv1_bwd_data(dp1, code1, w, h, wd):
     _need_gpu(dp1, code1, w)
     assert dp1.is_contiguous() and code1.is_contiguous() and w.is_contiguous() and w.numel() == 64
     b = dp1.shape[0]
-    assert dp1.shape == (b, (h + 1) // 2, (wd + 1) // 2, 16) and code1.shape == dp1.shape[:3]
+    assert dp1.shape == (b, (h + 1) // 2, (wd + 1) // 2, 16)
+    assert code1.shape == (b, (h + 1) // 2, simnn_code1_width((wd + 1) // 2))
     dx = torch.empty((b, h, wd), dtype=torch.float32, device=dp1.device)
     _call("gdm_simnn_conv1_bwd_data", _p(dp1), _p(code1), _p(w), b, h, wd, _p(dx), gdm_dtype(dp1), _stream())
     return dx

@@ -362,7 +362,7 @@ class SimnnTrainer(_TrainerBase):
         h1, w1s = (h + 1) // 2, (w + 1) // 2
         adt = ops.torch_dtype(dt)
         p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=real.device)
-        code1 = torch.empty((2 * b, h1, w1s), dtype=torch.int64, device=real.device)
+        code1 = torch.empty((2 * b, h1, ops.simnn_code1_width(w1s)), dtype=torch.int64, device=real.device)
         ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
         if not bridge:
             # tensor stand-in for the bridge: the generator is independent of the discriminator step and runs beside
@@ -380,7 +380,7 @@ class SimnnTrainer(_TrainerBase):
         self._reduce_and_step()
         # --- "generator" step (SIMNN.py:322-331): D forward on fake with the updated weights, label 1.0
         p1g = torch.empty((b, h1, w1s, 16), dtype=adt, device=real.device)
-        code1g = torch.empty((b, h1, w1s), dtype=torch.int64, device=real.device)
+        code1g = torch.empty((b, h1, ops.simnn_code1_width(w1s)), dtype=torch.int64, device=real.device)
         ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1g, code1g))
         hid_g, saved_g = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1g, code1g))
         _prob, dh_g, _ = ops.simnn_head(hid_g, wf2, bf2, b, 1.0, 1.0, loss_out=self.loss_g, want_grad=not self.elide,
@@ -442,7 +442,7 @@ class SimnnTrainer(_TrainerBase):
         h1, w1s = (h + 1) // 2, (w + 1) // 2
         adt = ops.torch_dtype(dt)
         p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=real.device)
-        code1 = torch.empty((2 * b, h1, w1s), dtype=torch.int64, device=real.device)
+        code1 = torch.empty((2 * b, h1, ops.simnn_code1_width(w1s)), dtype=torch.int64, device=real.device)
         ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
         # branches fork after the first main-stream launch (see step)
         if with_generator:

@@ -140,13 +140,15 @@ int gdm_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n
 
 /* ---- model 1 discriminator, convolution trunk (SIMNN.py:123-125,136-139) ---------------------------------------
  * conv1: Conv2d(1,16,k2,s1,p1)+ReLU+MaxPool2 fused (aten::convolution/relu/max_pool2d_with_indices):
- *   x (B,H,W) fp32 -> p1 (B,H1,W1,16) channels-last `dtype`, code1 (B,H1,W1) uint64 = four 16-bit fields, field g
- *   (bits 16g..16g+15) for channels 4g..4g+3: bits [2r+1:2r] = argmax position (dy*2+dx, first maximum in scan
- *   order) of channel 4g+r, bit 8+r = that channel passes gradient (pooled value > 0); H1=(H+1)/2, W1=(W+1)/2.
- *   code1 is only ever read back by gdm_simnn_conv1_bwd_weight / gdm_simnn_conv2_bwd_fused.
+ *   x (B,H,W) fp32 -> p1 (B,H1,W1,16) channels-last `dtype`, code1 = B*H1*4*Q1 uint64 (Q1 = ceil(W1/4); 8 bytes per
+ *   pooled pixel, rows padded to whole quads of four pixels), an opaque image of 16-bit fields, one per (pixel, channel
+ *   group g of four): nibble k of a field belongs to channel 4g+k, bits [1:0] = argmax position (dy*2+dx, first maximum in
+ *   scan order), bit 2 = that channel passes gradient (pooled value > 0); fields are ordered
+ *   [image][pooled row][quad = pw/4][g][pw%4], pixels >= W1 of a row's last quad hold 0; H1=(H+1)/2, W1=(W+1)/2.
+ *   code1 is only ever read back by gdm_simnn_conv1_bwd_weight / _bwd_data / gdm_simnn_conv2_bwd_fused.
  * conv2: Conv2d(16,32,k3,s1,p1)+ReLU+MaxPool2 fused, implicit GEMM on MFMA:
- *   p1 -> p2 (B,H2,W2,32) channels-last, code2 (B,H2,W2,32) uint8 (0..3 = argmax position in scan order,
- *   4 = ReLU-dead), H2=H1/2, W2=W1/2.  The reference flattens channel-major (x.view(-1, 32*32*54), SIMNN.py:139);
+ *   p1 -> p2 (B,H2,W2,32) channels-last, code2 (B,H2,W2,16) uint8: one byte per channel pair (2j, 2j+1) =
+ *   8 * (c_even + 5 * c_odd), c = 0..3 argmax position in scan order, 4 = ReLU-dead; H2=H1/2, W2=W1/2.  The reference flattens channel-major (x.view(-1, 32*32*54), SIMNN.py:139);
  *   the host keeps fc1's weight permuted to the channels-last order instead (gdm_permute_pc), which is the same
  *   linear map.
  * conv2 weights are consumed from a packed image built by gdm_simnn_conv2_pack (forward and flipped-backward MFMA

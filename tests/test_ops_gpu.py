@@ -298,7 +298,7 @@ def test_simnn_conv_trunk_forward_backward(dt, b, h, w):
     _close(p1.float().permute(0, 3, 1, 2), a1, 1e-5 if dt == F32 else 1e-2, "conv1+relu+pool")
     pack = ops.simnn_conv2_pack(w2.detach().to(DEV), dt)
     p2, code2 = ops.simnn_conv2_fwd(p1, pack, b2.detach().to(DEV))
-    assert int(code2.max().item()) <= 4
+    assert code2.shape == p2.shape[:3] + (16,) and int(code2.max().item()) <= 8 * 24 and not bool((code2 % 8).any())
     up = torch.randn(a2.shape, generator=g)
     if dt == F32:
         _close(p2.permute(0, 3, 1, 2), a2, rt, "conv2+relu+pool")

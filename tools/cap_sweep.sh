@@ -1,6 +1,6 @@
 # Grid-cap sweep of the persistent conv kernels under the default (pipelined, graph-replayed) bench: two chains share the
 # chip, so the caps tuned for a kernel running alone are worth re-checking.  Prints ms/step per setting.
-run() { echo -n "$1: "; env $1 python bench.py --no-cpu-baseline --no-roofline --steps 40 --warmup 5 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"; }
+run() { echo -n "$1: "; env $1 python bench.py --no-cpu-baseline --no-secondary --no-roofline --steps 40 --warmup 5 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"; }
 run X=0
 run GDM_BD_CAP=384
 run GDM_BD_CAP=768
