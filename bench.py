@@ -42,7 +42,8 @@ def dominant_kernel(workload, dtype, hw, t):
         h2, w2 = h1 // 2, w1 // 2
         # fused conv2 data-gradient + conv1 weight-gradient kernel: reads the pooled gradient dp2 and its codes,
         # conv1's codes and the input window; writes nothing per sample (80 partial sums per workgroup)
-        nbytes = h2 * w2 * 32 * esz + h2 * w2 * 32 + h1 * w1 * 8 + h * w * 4
+        # (code2: one byte per channel PAIR since round 3)
+        nbytes = h2 * w2 * 32 * esz + h2 * w2 * 16 + h1 * w1 * 8 + h * w * 4
         return {"name": "gdm_simnn_conv2_bwd_fused", "kernel": "conv2_bwd_data_kernel<FUSE> (gdm_simnn_conv2_bwd_fused)",
                 "bytes_per_sample": nbytes, "flops_per_sample": 2.0 * h1 * w1 * 16 * 288}
     # model 2: the fused DiscriminatorCNN pass (forward + loss + backward of one sample inside LDS).  HBM sees the two

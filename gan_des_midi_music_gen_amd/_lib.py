@@ -56,6 +56,7 @@ SIGNATURES = {
     "gdm_act_bwd": (_I, [_P, _P, _I, _L, _I, _F, _P, _P]),
     "gdm_colsum": (_I, [_P, _I, _I, _I, _P, _P, _Z, _P]),
     "gdm_cast": (_I, [_P, _I, _P, _I, _L, _P]),
+    "gdm_nonfinite_count": (_I, [_P, _I, _L, _P, _P]),
     "gdm_simnn_conv1_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "gdm_simnn_conv2_pack_bytes": (_Z, [_I]),
     "gdm_simnn_conv2_pack": (_I, [_P, _I, _P, _P]),

@@ -818,3 +818,31 @@ extern "C" int gdm_concat_cols_multi(const gdm_concat_job* jobs, int n_jobs, voi
   GDM_LAUNCH_OK("gdm_concat_cols_multi");
   return GDM_OK;
 }
+
+// ---- non-finite detection (anomaly mode / check_finite) ----------------------------------------------------------------
+// The library is compiled with -fno-honor-nans (a NaN has no defined effect on the arithmetic: the issue-bound conv
+// epilogues save a canonicalisation per fmaxf), so "did a NaN or Inf enter or leave the step" is answered by looking at
+// the BITS of the tensors: exponent all ones.  counter[0] += number of non-finite elements (integer atomics: exact).
+namespace {
+__global__ __launch_bounds__(256) void nonfinite_count_kernel(const void* __restrict__ x, int dtype, int64_t n,
+                                                              int* __restrict__ counter) {
+  int c = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const uint32_t bits = dtype == GDM_BF16 ? (uint32_t)((const uint16_t*)x)[i] << 16 : ((const uint32_t*)x)[i];
+    c += (bits & 0x7f800000u) == 0x7f800000u ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c != 0) atomicAdd(counter, c);
+}
+}  // namespace
+
+extern "C" int gdm_nonfinite_count(const void* x, int dtype, int64_t n, int* counter, void* stream) {
+  GDM_REQUIRE(x && counter && n >= 0 && gdm_dtype_ok(dtype), "gdm_nonfinite_count: bad arguments");
+  if (n == 0) return GDM_OK;
+  int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(nonfinite_count_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, dtype, n, counter);
+  GDM_LAUNCH_OK("gdm_nonfinite_count");
+  return GDM_OK;
+}

@@ -739,22 +739,24 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
 //   table A: {selector for position 0, position 1}   table B: {position 2, position 3}   table C: {live channels, -}
 // A selector moves the even channel's bf16 gradient (bytes 0,1 of the packed pair) and/or the odd channel's (bytes 2,3)
 // to its place when that channel's argmax is the position, and writes zero (0x0c) otherwise.  25 entries x 8 B: two
-// entries share a 16-byte LDS slot only 16 entries apart -> a table read is at most 2-way conflicted.
-constexpr int C2T_BYTES = 3 * 256;
+// entries share a 16-byte LDS slot only 16 entries apart -> a table read is at most 2-way conflicted.  Table B sits
+// more than 2040 bytes behind table A so that the compiler cannot merge the two 8-byte reads of a pair into one
+// ds_read2_b64 (8 LDS cycles per wave instead of 2 + 2).
+constexpr int C2T_B = 2304, C2T_C = 256, C2T_BYTES = C2T_B + 256;
 __device__ __forceinline__ void code2_tables_init(uint32_t* tab) {
   const int e = threadIdx.x;
   if (e < 25) {
     const uint32_t c0 = e % 5, c1 = e / 5;
     auto sel = [&](uint32_t pos) { return (c0 == pos ? 0x0100u : 0x0c0cu) | (c1 == pos ? 0x03020000u : 0x0c0c0000u); };
     tab[2 * e] = sel(0); tab[2 * e + 1] = sel(1);
-    tab[64 + 2 * e] = sel(2); tab[64 + 2 * e + 1] = sel(3);
-    tab[128 + 2 * e] = (c0 != 4 ? 0x0100u : 0x0c0cu) | (c1 != 4 ? 0x03020000u : 0x0c0c0000u);
-    tab[128 + 2 * e + 1] = 0x0c0c0c0cu;
+    tab[C2T_B / 4 + 2 * e] = sel(2); tab[C2T_B / 4 + 2 * e + 1] = sel(3);
+    tab[C2T_C / 4 + 2 * e] = (c0 != 4 ? 0x0100u : 0x0c0cu) | (c1 != 4 ? 0x03020000u : 0x0c0c0000u);
+    tab[C2T_C / 4 + 2 * e + 1] = 0x0c0c0c0cu;
   }
 }
 // the four position-masked copies of one packed channel pair gw whose pair byte is `off8` (already a table offset)
 __device__ __forceinline__ void code2_expand_pair(const unsigned char* tab, uint32_t off8, uint32_t gw, uint32_t (&out)[4]) {
-  const u32x2 sa = *(const u32x2*)(tab + off8), sb = *(const u32x2*)(tab + 256 + off8);
+  const u32x2 sa = *(const u32x2*)(tab + off8), sb = *(const u32x2*)(tab + C2T_B + off8);
   out[0] = __builtin_amdgcn_perm(0u, gw, sa[0]);
   out[1] = __builtin_amdgcn_perm(0u, gw, sa[1]);
   out[2] = __builtin_amdgcn_perm(0u, gw, sb[0]);
@@ -1092,10 +1094,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
   auto step = [&](BdStepRegs<T, FUSE, XVEC>& rg, const Pos& cur, const Pos& nxt) {
     const int b = cur.b, c0 = cur.c0, rq = cur.rq, rq_first = cur.rq_first;
     // ---- consume the prefetched registers into the LDS images of this step
-#ifdef GDM_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(3);
-#endif
     bd_expand<T, FUSE, XVEC>(rg, ln, rq, dc_s, tab_s);
     uint64_t codes[FUSE ? 4 : 1];
     if constexpr (FUSE) {
@@ -1512,7 +1511,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
           const uint32_t off8 = (cd >> (8 * w)) & 0xffu;
           code2_expand_pair(tab_s, off8, gv[w], ex[w]);
           // bias gradient: channels whose pooled value was live
-          const uint32_t g = __builtin_amdgcn_perm(0u, gv[w], *(const uint32_t*)(tab_s + 512 + off8));
+          const uint32_t g = __builtin_amdgcn_perm(0u, gv[w], *(const uint32_t*)(tab_s + C2T_C + off8));
           bsum[2 * w] += __builtin_bit_cast(float, g << 16);
           bsum[2 * w + 1] += __builtin_bit_cast(float, g & 0xffff0000u);
         }

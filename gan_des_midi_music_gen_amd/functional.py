@@ -125,6 +125,46 @@ def simnn_disc_backward(saved, dz, pack, wf1p, wf2, dt, out=None, x_pair=None, w
     return dw1, db1, dw2, db2, dwf1, dbf1, dwf2, dbf2, dx
 
 
+def _anomaly_guard(cls):
+    """torch.autograd.set_detect_anomaly(True) -- the reference's entry point sets it (network_tests.py:211) -- makes
+    torch raise when a backward function returns NaN.  The kernels behind these Functions are compiled without NaN
+    semantics, so under anomaly mode the Functions look at the bits themselves (ops.assert_finite: one small counting
+    launch per tensor + a host read -- anomaly mode is a debugging mode in torch too): inputs and outputs of forward,
+    and every gradient backward returns.  Raises ops.NonFiniteError (a RuntimeError, like torch's)."""
+    fwd, bwd = cls.forward, cls.backward
+
+    def _tensors(xs):
+        out = []
+        for x in xs:
+            if isinstance(x, torch.Tensor) and x.is_floating_point() and x.is_cuda:
+                out.append(x.detach())
+            elif isinstance(x, (tuple, list)):
+                out.extend(_tensors(x))
+        return out
+
+    def forward(ctx, *args):
+        if not torch.is_anomaly_enabled():
+            return fwd(ctx, *args)
+        ops.assert_finite(_tensors(args), f"Function '{cls.__name__}' received")
+        out = fwd(ctx, *args)
+        ops.assert_finite(_tensors(out if isinstance(out, (tuple, list)) else (out,)), f"Function '{cls.__name__}' returned")
+        return out
+
+    def backward(ctx, *grads):
+        out = bwd(ctx, *grads)
+        if torch.is_anomaly_enabled():
+            ops.assert_finite(_tensors(grads), f"Function '{cls.__name__}Backward' received")
+            ops.assert_finite(_tensors(out if isinstance(out, (tuple, list)) else (out,)),
+                              f"Function '{cls.__name__}Backward' returned nan values:")
+        return out
+
+    cls.forward = staticmethod(forward)
+    cls.backward = staticmethod(backward)
+    return cls
+
+
+
+@_anomaly_guard
 class SimnnDiscFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, wf1, bf1, wf2, bf2, dt):
@@ -324,6 +364,7 @@ def simnn_gen_backward(saved, dimg, ws, bns, dt, need_dnoise=True):
     return dnoise, dws, dbn
 
 
+@_anomaly_guard
 class SimnnGenFn(torch.autograd.Function):
     """args: noise, w1..w4, (gamma,beta) x3, then non-differentiable: buffers tuple, training flag, dtype."""
 
@@ -392,6 +433,7 @@ def mlp_bn_sigmoid_backward(saved, dout, layers, dt, need_dx=True):
     return d, grads
 
 
+@_anomaly_guard
 class MlpBnSigmoidFn(torch.autograd.Function):
     """args: x, then per layer (W, b, gamma, beta) x L, then buffers tuple ((rm, rv, nbt) x L), training, dtype."""
 
@@ -463,6 +505,7 @@ def dcnn_backward(saved, dlogits, w2, wf, dt, w1_for_dx=None, in_hw=None):
     return dw1, db1, dw2, db2, dwf, dbf, dx
 
 
+@_anomaly_guard
 class DcnnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, w1, b1, w2, b2, wf, bf, dt):
@@ -511,6 +554,7 @@ def mlp_leaky_backward(saved, dout, layers, dt, need_dx=False):
     return d, grads
 
 
+@_anomaly_guard
 class MlpLeakyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, *rest):
@@ -577,6 +621,7 @@ def simnn_net_backward(saved, dout, w1, w2, wf1, wf2, dt, need_dx=False):
     return dw1, db1, dw2, db2, dwf1, dbf1, dwf2, dbf2, dx
 
 
+@_anomaly_guard
 class SimnnNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, wf1, bf1, wf2, bf2, dt):

@@ -289,7 +289,15 @@ class TestMultiModalGAN(unittest.TestCase):
         and the DES bridge are absent (they are not part of this build)."""
         if not torch.cuda.is_available():
             self.skipTest("needs a HIP device")
-        return training_loop(batch_size, num_epochs=1, steps_per_epoch=4, log=lambda *_a: None)
+        # network_tests.py:211: the reference's loop runs under anomaly detection; here that makes every iteration check
+        # its inputs, losses and discriminator state for NaN / Inf (train._TrainerBase.check_finite).  The reference
+        # leaves the flag set; this entry point restores what it found.
+        was = torch.is_anomaly_enabled()
+        torch.autograd.set_detect_anomaly(True)
+        try:
+            return training_loop(batch_size, num_epochs=1, steps_per_epoch=4, log=lambda *_a: None)
+        finally:
+            torch.autograd.set_detect_anomaly(was)
 
 
 if __name__ == "__main__":

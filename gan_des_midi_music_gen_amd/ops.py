@@ -347,6 +347,30 @@ def cast(x, dt):
     return out
 
 
+class NonFiniteError(RuntimeError):
+    """A NaN or Inf entered or left a step (what torch's anomaly mode reports in the reference, network_tests.py:211)."""
+
+
+def nonfinite_count(tensors, counter=None):
+    """counter (1,) int32 device tensor += number of NaN / Inf elements in ``tensors`` (fp32 / bf16 device tensors);
+    enqueued on the current stream, no synchronisation.  Returns the counter."""
+    tensors = [t for t in tensors if t is not None and t.numel() > 0]
+    _need_gpu(*tensors)
+    if counter is None:
+        counter = torch.zeros(1, dtype=torch.int32, device=tensors[0].device)
+    for t in tensors:
+        t = t if t.is_contiguous() else t.contiguous()
+        _call("gdm_nonfinite_count", _p(t), gdm_dtype(t), t.numel(), _p(counter), _stream())
+    return counter
+
+
+def assert_finite(tensors, what):
+    """Synchronising check used under torch.autograd.set_detect_anomaly(True): raises NonFiniteError naming ``what``."""
+    n = int(nonfinite_count(tensors).item())
+    if n:
+        raise NonFiniteError(f"{what}: {n} non-finite value(s) (NaN / Inf)")
+
+
 # ------------------------------------------------------------------------------------------ model 1 conv trunk
 def simnn_code1_width(w1):
     """Last dimension of the int64 tensor that holds conv1's pool / ReLU codes of a (.., w1)-wide pooled map: 8 bytes

@@ -194,6 +194,36 @@ class _TrainerBase:
         if params is not None:
             self._refresh_operands()
 
+    # ---- non-finite values -------------------------------------------------------------------------------------------
+    # The reference runs under torch.autograd.set_detect_anomaly(True) (network_tests.py:211): a NaN raises there.  The
+    # kernels here are compiled without NaN semantics (a NaN / Inf in an input or weight has NO defined effect on the
+    # results -- it may propagate or be flushed by an fmaxf), so the defined behaviour is: (a) with anomaly mode on,
+    # every eager ``step`` counts the non-finite elements of its inputs, losses and discriminator parameters on the
+    # device and raises ops.NonFiniteError before returning; (b) ``check_finite(*tensors)`` does the same on request
+    # (graph replays, anomaly mode off).
+    def _watch(self, *tensors):
+        if torch.is_anomaly_enabled():
+            if getattr(self, "_nf", None) is None:
+                self._nf = torch.zeros(1, dtype=torch.int32, device=self.d.flat.device)
+            ops.nonfinite_count([t for t in tensors if isinstance(t, torch.Tensor)], self._nf)
+
+    def check_finite(self, *tensors):
+        """Raise ops.NonFiniteError if the last losses, the discriminator's parameters / Adam moments, anything watched
+        since the last check (anomaly mode) or any of ``tensors`` (e.g. the batch just used) holds a NaN or Inf.
+        Synchronises."""
+        if getattr(self, "_nf", None) is None:
+            self._nf = torch.zeros(1, dtype=torch.int32, device=self.d.flat.device)
+        ops.nonfinite_count([self.loss_g, self.loss_d, self.d.flat, self.d.exp_avg, self.d.exp_avg_sq, *tensors], self._nf)
+        n = int(self._nf.item())
+        self._nf.zero_()
+        if n:
+            raise ops.NonFiniteError(f"{type(self).__name__}: {n} non-finite value(s) in inputs, losses, discriminator "
+                                     f"parameters or optimizer state after iteration {self.iterations}")
+
+    def _anomaly_check(self):
+        if torch.is_anomaly_enabled() and not torch.cuda.is_current_stream_capturing():
+            self.check_finite()
+
     def disc_loss_value(self):
         """Global-batch mean of the last discriminator loss (the SUM over ranks rode the gradient all-reduce)."""
         return self.loss_d.item() / self.world
@@ -330,6 +360,7 @@ class SimnnTrainer(_TrainerBase):
         w1, b1, w2, b2, wf1, bf1, wf2, bf2 = self.d.views
         gv = self.d.grad_views
         real = Fn._f32c(real)
+        self._watch(real, noise, fake)
         b, h, w = real.shape
         main = torch.cuda.current_stream()
         side = self._streams(real.device) if self.overlap else None
@@ -396,6 +427,7 @@ class SimnnTrainer(_TrainerBase):
         # gen_opt.step(): every generator .grad is None -> no-op
         self.iterations += 1
         del keep
+        self._anomaly_check()
         return self.loss_d, self.loss_g
 
     # ---- the same iteration, generator half of iteration i beside the discriminator step of iteration i+1 ----------
@@ -689,10 +721,12 @@ class MmganTrainer(_TrainerBase):
         The iteration is three pieces -- everything up to the gradient (``_part_a``), the data-parallel exchange, Adam and
         the generator step (``_part_b``) -- so that with more than one rank the two compute pieces can be replayed as
         hipGraphs around the eager collective (``capture`` / ``replay``)."""
+        self._watch(piano_roll, durations, beats, noise1, noise2, fake_a, fake_b, g1_in_a, g1_in_b)
         self._part_a(piano_roll, durations, beats, noise1, noise2, fake_a, g1_in_a, g1_in_b)
         self._reduce()
         self._part_b(piano_roll, beats, noise1, noise2, fake_b, g1_in_b)
         self.iterations += 1
+        self._anomaly_check()
         return self.loss_d, self.loss_g
 
     def _sides(self, dev):

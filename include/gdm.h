@@ -137,6 +137,11 @@ int gdm_act_bwd(const void* dout, const void* out, int dtype, int64_t n, int act
 int gdm_colsum(const void* x, int dtype, int rows, int cols, float* out, void* workspace, size_t workspace_bytes,
                void* stream);
 int gdm_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* counter[0] (device int) += number of NaN / +-Inf elements of x (bit test: the library's arithmetic is compiled
+ * without NaN semantics).  What torch.autograd.set_detect_anomaly(True) (network_tests.py:211) turns into an exception
+ * in the reference is found with this: the host side checks inputs, parameters, losses and gradients when anomaly
+ * mode is on, or on request (check_finite()). */
+int gdm_nonfinite_count(const void* x, int dtype, int64_t n, int* counter, void* stream);
 
 /* ---- model 1 discriminator, convolution trunk (SIMNN.py:123-125,136-139) ---------------------------------------
  * conv1: Conv2d(1,16,k2,s1,p1)+ReLU+MaxPool2 fused (aten::convolution/relu/max_pool2d_with_indices):

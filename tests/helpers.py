@@ -37,3 +37,44 @@ def rel_l2(a, b):
     a = torch.as_tensor(a).double().cpu().flatten()
     b = torch.as_tensor(b).double().cpu().flatten()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def record(name, **kv):
+    """Append a measured deviation to gpurun_out/parity_r03.jsonl (when that directory exists): the numbers DESIGN.md
+    quotes next to the bounds."""
+    import json
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_r03.jsonl"), "a") as f:
+            f.write(json.dumps({"test": name, **kv}) + "\n")
+
+
+class _RoundOperand(torch.autograd.Function):
+    """value rounded to bf16 on the way forward (an operand the kernel reads in bf16), gradient untouched"""
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGradient(torch.autograd.Function):
+    """identity forward; the gradient that flows back through this point is rounded to bf16 (a gradient map the
+    kernels store in bf16 / a gradient operand they read in bf16)"""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def round_operand(x):
+    return _RoundOperand.apply(x)
+
+
+def round_gradient(x):
+    return _RoundGradient.apply(x)

@@ -11,7 +11,7 @@ Stated bf16 bounds (DESIGN.md section 2 repeats the consta
   model 1, one iteration at the benchmark batch (B=256): both losses within SIMNN_LOSS_TOL.
   model 2, B=16, T=50, 50 teacher-forced iterations: see the test (Adam lr 0.01 on un-normalised velocities: losses
       reach O(10..100) and free-running trajectories are chaotic; compared relatively, MMGAN_LOSS_RTOL).
-Measured deviations are appended to gpurun_out/parity_r02.jsonl (when that directory exists) for DESIGN.md.
+Measured deviations are appended to gpurun_out/parity_r03.jsonl (when that directory exists) for DESIGN.md.
 """
 import json
 import os
@@ -38,11 +38,7 @@ MMGAN_LOSS_RTOL = 2e-2       # measured 4.5e-3 (disc_loss), 7.4e-3 (gen_loss) ov
 MMGAN_GEN_TOL = 1e-3         # measured 8e-5: split-bf16 (hi + lo) operands in the fused Linear+BatchNorm+Sigmoid block
 
 
-def _record(name, **kv):
-    d = os.path.join(ROOT, "gpurun_out")
-    if os.path.isdir(d):
-        with open(os.path.join(d, "parity_r02.jsonl"), "a") as f:
-            f.write(json.dumps({"test": name, **kv}) + "\n")
+from helpers import record as _record  # noqa: E402
 
 
 def _simnn_pair(hw, seed=0):
@@ -115,6 +111,69 @@ def test_simnn_bf16_one_iteration_at_the_benchmark_batch():
     _record("simnn_bf16_b256_one_iteration", d_loss=(dl.item(), want[0]), g_loss=(gl.item(), want[1]))
     assert abs(dl.item() - want[0]) <= SIMNN_LOSS_TOL and abs(gl.item() - want[1]) <= SIMNN_LOSS_TOL
     assert (tr.last_generated.float().cpu() - want[2]).abs().max().item() <= SIMNN_GEN_TOL * want[2].abs().max().item()
+
+
+@pytest.mark.parametrize("b,what", [(16, "C1: the reference's own geometry and batch (SIMNN.py:236, 126)"),
+                                    (128, "C5: spectrogram-discriminator path at batch 128")])
+def test_simnn_bf16_trainer_at_the_reference_geometry(b, what):
+    """BASELINE configs[0] / configs[4]: 128x216 windows (the geometry Discriminator.fc1 is hard-wired to,
+    GAN_DES/SIMNN.py:126,139), through the bf16 trainer on the benchmarked schedule (pipelined calls + hipGraph replay),
+    three free-running iterations beside oracle.steps.simnn_iteration: losses within SIMNN_LOSS_TOL, generated matrices
+    within SIMNN_GEN_TOL, and the discriminator's first Adam steps in the oracle's direction."""
+    hw, n = (128, 216), 3
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    rg, rd, gen, disc = _simnn_pair(hw, seed=3)
+    init = {k: v.detach().clone() for k, v in rd.named_parameters()}
+    g_opt, d_opt = ost.Adam(rg.parameters(), 2e-5, (0.5, 0.999)), ost.Adam(rd.parameters(), 2e-5, (0.5, 0.999))
+    tr = SimnnTrainer(gen, disc, compute_dtype="bf16")
+    real, fake, noise = synthetic.simnn_inputs(b, hw, seed=2024 + b)
+    rd_, fk_, nz_ = real.to(DEV), fake.to(DEV), noise.to(DEV)
+    tr.capture(rd_, nz_, fk_, pipelined=True)               # two eager iterations, then the recorded one
+    got_d, got_g = [], []
+    for _ in range(n):
+        dl, gl = tr.replay()
+        got_d.append(dl.item()); got_g.append(gl.item())
+    got_g.append(tr.flush().item())
+    want = [ost.simnn_iteration(rg, rd, g_opt, d_opt, real, noise, fake) for _ in range(n + 2)]
+    dd = np.abs(np.array(got_d) - np.array([w[0] for w in want[2:]]))
+    dg = np.abs(np.array(got_g) - np.array([w[1] for w in want[1:]]))   # got_g[0] = gen_loss of the 2nd warm-up iteration
+    gen_err = (tr.last_generated.float().cpu() - want[-1][2]).abs().max().item() / want[-1][2].abs().max().item()
+    upd = {k: rel_l2(p.detach().cpu() - init[k], dict(rd.named_parameters())[k].detach() - init[k])
+           for k, p in disc.named_parameters()}
+    _record("simnn_bf16_128x216", batch=b, max_d_loss_err=float(dd.max()), max_g_loss_err=float(dg.max()),
+            generated_rel_err=gen_err, update_rel_l2=upd)
+    assert dd.max() <= SIMNN_LOSS_TOL and dg.max() <= SIMNN_LOSS_TOL, (what, dd.max(), dg.max())
+    assert gen_err <= SIMNN_GEN_TOL, gen_err
+    for k, r in upd.items():
+        assert r <= 0.3, (k, r)           # five sign-like Adam steps (measured <= 0.19, conv2.bias at B = 16)
+
+
+def test_simnn_bf16_properties_at_128x64():
+    """BASELINE configs[0] words its input as 128x64 (a width the reference's fc1 does not accept; here
+    Discriminator(input_hw=(128, 64))): size-independent properties of one bf16 trainer iteration at B = 16 --
+    determinism, the 2B-batch discriminator step = the sum of its halves, faithful == elided, finite losses that are the
+    BCE of the probabilities the module itself reports."""
+    hw, b = (128, 64), 16
+    real, fake, noise = synthetic.simnn_inputs(b, hw, seed=99, device=DEV)
+
+    def run(elide):
+        torch.manual_seed(4)
+        gen = SIMNN.Generator().apply(SIMNN.weights_init).to(DEV)
+        disc = SIMNN.Discriminator(input_hw=hw).apply(SIMNN.weights_init).to(DEV)
+        disc.compute_dtype = "bf16"
+        with torch.no_grad():
+            p_real, p_fake = disc(real).reshape(-1), disc(fake).reshape(-1)
+        tr = SimnnTrainer(gen, disc, compute_dtype="bf16", elide_dead_backward=elide)
+        dl, gl = tr.step(real, noise, fake)
+        torch.cuda.synchronize()
+        return dl.item(), gl.item(), [v.detach().clone() for v in tr.d.views], p_real, p_fake, tr.last_generated.clone()
+
+    a, c, e = run(False), run(False), run(True)
+    assert a[:2] == c[:2] and all(torch.equal(u, v) for u, v in zip(a[2], c[2])), "deterministic"
+    assert a[:2] == e[:2] and all(torch.equal(u, v) for u, v in zip(a[2], e[2])), "faithful == elided"
+    want_d = (ost.bce_with_logits(a[3].cpu(), torch.full((b,), 0.9)) + ost.bce_with_logits(a[4].cpu(), torch.full((b,), 0.1))).item()
+    assert np.isfinite(a[0]) and np.isfinite(a[1]) and abs(a[0] - want_d) < 1e-4, (a[0], want_d)
+    assert a[5].shape == (b, 1, 20, 20) and bool(((a[5] > 0) & (a[5] < 1)).all())
 
 
 def _mm_pair(seed, t=50):
