@@ -82,6 +82,8 @@ def parse():
                     help="model 1: run the generator half of an iteration inside the same call (SimnnTrainer.step)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no concurrent branches)")
+    ap.add_argument("--pieces", action="store_true",
+                    help="model 1 on one rank: replay the five-graph form N > 1 ranks use (around the all-reduces)")
     return ap.parse_args()
 
 
@@ -154,8 +156,12 @@ def build_simnn(args, rank, dev):
         # to itself, so the HIP events around its launches measure the kernel, not the time-sharing of two chains
         return tr.step(real, noise, fake)
     step = eager
-    if not args.no_graph and tr.world == 1:
-        tr.capture(real, noise, fake, pipelined=pipelined)      # the whole call (all stream branches) as one hipGraph
+    if not args.no_graph and (tr.world == 1 or (args.pieces and pipelined)):
+        # one rank: the whole call as one hipGraph (+ the generator forward as a graph of its own).  N ranks launch
+        # eagerly: the five-graph form around the two all-reduces (--pieces, SimnnTrainer._capture_pieces) is
+        # bit-identical but measured SLOWER than the eager multi-stream iteration on one rank (0.755 vs 0.631 ms: the
+        # graph boundaries and cross-stream joins cost more than ~60 host launches that the host issues ahead anyway)
+        tr.capture(real, noise, fake, pipelined=pipelined, pieces=args.pieces)
         step = tr.replay
     elif pipelined:
         eager()        # every timed call must find a pending generator half, like every later one
@@ -297,8 +303,10 @@ def loss_parity(args, parity, dev):
 
 
 def launch_description(args, world, tr):
-    if args.no_graph or (world > 1 and args.workload == "simnn"):
-        return "eager"
+    if args.no_graph or (world > 1 and args.workload == "simnn" and getattr(tr, "_pieces", None) is None):
+        return "eager (multi-stream)"
+    if getattr(tr, "_pieces", None) is not None:
+        return "5 fork-free hipGraphs (generator, generator half, forward+head+fc1 dW, backward, Adam) around 2 eager all-reduces"
     if world > 1:
         return "2 hipGraphs + eager all-reduce per iteration"
     if getattr(tr, "_graph_gen", None) is not None:

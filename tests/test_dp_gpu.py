@@ -78,6 +78,29 @@ for kind in ("eager", "graph"):
     out["mmgan_bf16_" + kind] = {"d_loss": mt.disc_loss_value(), "g_loss": mt.gen_loss_global(),
                                  "fc": mm.discriminator.fc.weight.detach().cpu(),
                                  "c1": mm.discriminator.conv1.weight.detach().cpu()}
+# model 1 on the benchmarked path (bf16, pipelined schedule): eager calls vs the five-graph replay around the two eager
+# collectives (train.SimnnTrainer._capture_pieces) -- what N > 1 ranks run in bench.py
+real, fake, noise = (t[lo:hi].contiguous() for t in synthetic.simnn_inputs(GB, hw, seed=970, device=dev))
+for kind in ("eager", "pieces"):
+    torch.manual_seed(0)
+    gen = SIMNN.Generator().apply(SIMNN.weights_init).to(dev)
+    disc = SIMNN.Discriminator(input_hw=hw).apply(SIMNN.weights_init).to(dev)
+    tg = SimnnTrainer(gen, disc, compute_dtype="bf16")
+    if kind == "pieces":
+        gg = tg.capture(real, noise, fake, pipelined=True, pieces=True)     # two eager iterations inside
+        assert isinstance(gg, dict) and len(gg) == 5
+        for _ in range(3):
+            tg.replay()
+    else:
+        for _ in range(5):
+            tg.step_pipelined(real, noise, fake)
+    torch.cuda.synchronize()
+    g_mid = tg.gen_loss_global()
+    tg.flush()
+    torch.cuda.synchronize()
+    out["simnn_bf16_" + kind] = {"d_loss": tg.disc_loss_value(), "g_loss": tg.gen_loss_global(), "g_loss_mid": g_mid,
+                                 "fc1": disc.fc1.weight.detach().cpu(), "c1": disc.conv1.weight.detach().cpu(),
+                                 "gen": tg.last_generated.detach().cpu(), "bn": gen.batch_norm2.running_var.detach().cpu()}
 if rank == 0:
     torch.save(out, os.environ["GDM_OUT"])
 if world > 1:
@@ -120,6 +143,10 @@ def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path):
         e, g = run["mmgan_bf16_eager"], run["mmgan_bf16_graph"]
         assert e["d_loss"] == g["d_loss"] and e["g_loss"] == g["g_loss"], (e["d_loss"], g["d_loss"])
         assert torch.equal(e["fc"], g["fc"]) and torch.equal(e["c1"], g["c1"])
+        e, g = run["simnn_bf16_eager"], run["simnn_bf16_pieces"]
+        assert e["d_loss"] == g["d_loss"] and e["g_loss"] == g["g_loss"] and e["g_loss_mid"] == g["g_loss_mid"]
+        for k in ("fc1", "c1", "gen", "bn"):
+            assert torch.equal(e[k], g[k]), ("model 1 pieces replay vs eager", k)
     for model in ("simnn", "simnn_pipelined", "mmgan"):
         a, b = one[model], two[model]
         assert abs(a["d_loss"] - b["d_loss"]) < 1e-5 * max(1.0, abs(a["d_loss"])), (model, a["d_loss"], b["d_loss"])
