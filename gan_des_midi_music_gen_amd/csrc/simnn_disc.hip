@@ -742,7 +742,11 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
 // entries share a 16-byte LDS slot only 16 entries apart -> a table read is at most 2-way conflicted.  Table B sits
 // more than 2040 bytes behind table A so that the compiler cannot merge the two 8-byte reads of a pair into one
 // ds_read2_b64 (8 LDS cycles per wave instead of 2 + 2).
-constexpr int C2T_B = 2304, C2T_C = 256, C2T_BYTES = C2T_B + 256;
+// Tables A' / B' hold the same selectors with the two pooling COLUMNS swapped ({position 1, 0} / {3, 2}): lanes whose
+// pooled pixel has an odd column index expand through them and store their first record one column to the right, their
+// second one to the left -- two neighbouring pooled pixels (128 bytes apart in a 64-byte-record image, i.e. on the same
+// 32 store banks) then hit opposite halves of the bank window: every expansion ds_write_b128 was 2-way conflicted.
+constexpr int C2T_SWAP = 256, C2T_C = 512, C2T_B = 2304, C2T_BYTES = C2T_B + 512;
 __device__ __forceinline__ void code2_tables_init(uint32_t* tab) {
   const int e = threadIdx.x;
   if (e < 25) {
@@ -750,6 +754,8 @@ __device__ __forceinline__ void code2_tables_init(uint32_t* tab) {
     auto sel = [&](uint32_t pos) { return (c0 == pos ? 0x0100u : 0x0c0cu) | (c1 == pos ? 0x03020000u : 0x0c0c0000u); };
     tab[2 * e] = sel(0); tab[2 * e + 1] = sel(1);
     tab[C2T_B / 4 + 2 * e] = sel(2); tab[C2T_B / 4 + 2 * e + 1] = sel(3);
+    tab[C2T_SWAP / 4 + 2 * e] = sel(1); tab[C2T_SWAP / 4 + 2 * e + 1] = sel(0);
+    tab[(C2T_B + C2T_SWAP) / 4 + 2 * e] = sel(3); tab[(C2T_B + C2T_SWAP) / 4 + 2 * e + 1] = sel(2);
     tab[C2T_C / 4 + 2 * e] = (c0 != 4 ? 0x0100u : 0x0c0cu) | (c1 != 4 ? 0x03020000u : 0x0c0c0000u);
     tab[C2T_C / 4 + 2 * e + 1] = 0x0c0c0c0cu;
   }
@@ -905,11 +911,13 @@ __device__ __forceinline__ void bd_expand(const BdStepRegs<T, FUSE, XVEC>& rg, c
     if constexpr (sizeof(T) == 2) {
       const u32x4 gv = __builtin_bit_cast(u32x4, rg.g[k][0]);
       uint32_t ex[4][4];                                                  // [channel pair][position]
+      const int odd = pcol & 1;                                           // odd pooled column: columns swapped (tables A'/B')
+      const unsigned char* tab_l = tab + (odd ? C2T_SWAP : 0);
 #pragma unroll
-      for (int w = 0; w < 4; ++w) code2_expand_pair(tab, (cd >> (8 * w)) & 0xffu, gv[w], ex[w]);
+      for (int w = 0; w < 4; ++w) code2_expand_pair(tab_l, (cd >> (8 * w)) & 0xffu, gv[w], ex[w]);
 #pragma unroll
       for (int dx = 0; dx < 2; ++dx) {
-        const int sc = 2 * pcol + dx;                                         // stored column
+        const int sc = 2 * pcol + (dx ^ odd);                                 // stored column
         const int piece = og ^ ((sc >> 1) & 2);                               // swizzled 16-byte slot of the record
         T* dst = dc_s + (slot * BD_WPX + sc) * S32 + 8 * piece;
 #pragma unroll
@@ -1506,10 +1514,12 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
       if constexpr (sizeof(T) == 2) {
         const u32x4 gv = __builtin_bit_cast(u32x4, rg.g[0]);
         uint32_t ex[4][4];                                   // [channel pair][position]
+        const int odd = dpcol & 1;                           // odd pooled column: columns swapped (see Code2 tables)
+        const unsigned char* tab_l = tab_s + (odd ? C2T_SWAP : 0);
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const uint32_t off8 = (cd >> (8 * w)) & 0xffu;
-          code2_expand_pair(tab_s, off8, gv[w], ex[w]);
+          code2_expand_pair(tab_l, off8, gv[w], ex[w]);
           // bias gradient: channels whose pooled value was live
           const uint32_t g = __builtin_amdgcn_perm(0u, gv[w], *(const uint32_t*)(tab_s + C2T_C + off8));
           bsum[2 * w] += __builtin_bit_cast(float, g << 16);
@@ -1517,7 +1527,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_weight_kernel(const T* __restri
         }
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-          const int col = 2 * dpcol + dx;
+          const int col = 2 * dpcol + (dx ^ odd);
           T* dst = dc_s + (2 * dprow * COLS + col) * S32 + 8 * BW<T>::dcpiece(og, col);
 #pragma unroll
           for (int dy = 0; dy < 2; ++dy)
