@@ -22,6 +22,11 @@ class LinearBnJob(_c.Structure):
                [(n, _I) for n in ("M", "N", "K", "groups", "stat_repeats")]
 
 
+class DcnnAdam(_c.Structure):
+    """gdm_dcnn_adam (include/gdm.h)."""
+    _fields_ = [("param", _P * 6), ("exp_avg", _P * 6), ("exp_avg_sq", _P * 6), ("hyper", _P), ("done", _P)]
+
+
 class ConcatJob(_c.Structure):
     """gdm_concat_job (include/gdm.h)."""
     _fields_ = [("a", _P), ("b", _P), ("out", _P), ("M", _I), ("Ka", _I), ("Kb", _I)]
@@ -82,6 +87,7 @@ SIGNATURES = {
     "gdm_dcnn_pack": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "gdm_dcnn_fused_workspace_bytes": (_Z, [_I, _I, _I]),
     "gdm_dcnn_fused": (_I, [_P, _I, _P, _P, _I, _I, _F, _F, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "gdm_dcnn_fused_adam": (_I, [_P, _I, _P, _P, _I, _I, _F, _F, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "gdm_im2col": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P]),
     "gdm_col2im": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P]),
     "gdm_permute_pc": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),

@@ -71,6 +71,22 @@ __device__ __forceinline__ float act_grad_from_out(float o, int act, float slope
   }
 }
 
+// One Adam element -- THE expression every kernel that applies the optimizer uses (pointwise.hip's three kernels and the
+// model-2 slab sum that applies the step itself).  The multiply-adds are written out: left to the compiler, contraction
+// differed from kernel to kernel and the same update came out one ulp apart.
+__device__ __forceinline__ void adam_element(float& p, float& m, float& v, float g, float gscale, float w1, float beta2,
+                                             float omb2, float eps, float step_size, float bc2_sqrt) {
+#pragma clang fp contract(off)
+  const float gj = g * gscale;
+  const float d = gj - m;
+  const float mj = (w1 < 0.5f) ? __builtin_fmaf(w1, d, m) : __builtin_fmaf(-(1.f - w1), d, gj);
+  const float vj = __builtin_fmaf(omb2 * gj, gj, v * beta2);
+  const float denom = sqrtf(vj) / bc2_sqrt + eps;
+  p = __builtin_fmaf(-step_size, mj / denom, p);
+  m = mj;
+  v = vj;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

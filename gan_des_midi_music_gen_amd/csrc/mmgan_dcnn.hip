@@ -568,11 +568,33 @@ struct DcnnSinks {
   float *dw1, *db1, *dw2, *db2, *dwfc, *dbfc;
   int T;
 };
+// FINISH == 2: the optimizer step rides the last level of the sum (one rank: nothing has to be exchanged between the
+// gradient and Adam).  The thread that owns a gradient element also owns its parameter: Adam on (p, m, v) -- the same
+// expression order as adam_dev_kernel -- and the updated value goes straight to its place(s) in the packed bf16 weight
+// images the next launch of the fused kernel reads (conv2's weight has two: forward image and parity-class backward
+// image).  Replaces slab sum -> adam_prep -> Adam -> re-pack (4 launches on the iteration's critical chain) by one.
+// The step counter of the device hyper-parameter record is advanced by the LAST workgroup to finish: every workgroup
+// has read the record before it can count itself finished.
+struct DcnnUpdate {
+  float *p[6], *m[6], *v[6];        // w1, b1, w2, b2, wfc, bfc: parameter, exp_avg, exp_avg_sq
+  float* hyper;                     // {step (int bits), lr, beta1, beta2, eps, grad_scale, step_size, sqrt(bc2)}
+  int* done;                        // workgroups-finished counter, zero between launches
+  __bf16* pack;
+};
 
-template <bool FINISH>
+template <int FINISH>
 __global__ __launch_bounds__(1024) void dcnn_slab_sum(const float* __restrict__ slabs, int nslabs, int per_group,
-                                                      int width, float* __restrict__ out, DcnnSinks k) {
+                                                      int width, float* __restrict__ out, DcnnSinks k, DcnnUpdate u) {
   __shared__ float part[16][64];
+  __shared__ float hy[2];
+  if constexpr (FINISH == 2) {
+    if (threadIdx.x == 1023) {         // derived terms in double, like adam_prep_kernel (and torch on the host)
+      const int step = __float_as_int(u.hyper[0]) + 1;
+      const double b1 = (double)u.hyper[2], b2 = (double)u.hyper[3];
+      hy[0] = (float)((double)u.hyper[1] / (1.0 - pow(b1, (double)step)));
+      hy[1] = (float)sqrt(1.0 - pow(b2, (double)step));
+    }
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
   const int k0 = blockIdx.y * per_group, k1 = min(nslabs, k0 + per_group);
@@ -591,21 +613,55 @@ __global__ __launch_bounds__(1024) void dcnn_slab_sum(const float* __restrict__ 
     float tsum = part[0][lane];
 #pragma unroll
     for (int w = 1; w < 16; ++w) tsum += part[w][lane];
-    if constexpr (!FINISH) {
+    if constexpr (FINISH == 0) {
       out[(int64_t)blockIdx.y * width + i] = tsum;
     } else {
-      if (i == S_LOSS) { k.loss[0] = (k.accumulate_loss ? k.loss[0] : 0.f) + tsum; return; }
-      if (!k.want_grad) return;
-      if (i == S_DBFC) k.dbfc[0] = tsum;
-      else if (i < S_DB2) k.db1[i - S_DB1] = tsum;
-      else if (i < S_PAD) k.db2[i - S_DB2] = tsum;
-      else if (i < S_DW1) return;
-      else if (i < S_DW2) k.dw1[i - S_DW1] = tsum;
-      else if (i < S_DWFC) k.dw2[i - S_DW2] = tsum;
-      else {                                       // slab: k' = pix*32 + c   ->   torch: c*P + pix
-        const Dims d(k.T);
+      const Dims d(k.T);
+      int which = -1, e = 0, pk0 = -1, pk1 = -1;                   // parameter, element, packed position(s)
+      const int total = W_ELEMS + d.KFC;                           // bf16 elements in front of the fp32 bias tail
+      if (i == S_LOSS) { k.loss[0] = (k.accumulate_loss ? k.loss[0] : 0.f) + tsum; }
+      else if (!k.want_grad) {}
+      else if (i == S_DBFC) { k.dbfc[0] = tsum; which = 5; e = 0; pk0 = 48; }
+      else if (i < S_DB2) { e = i - S_DB1; k.db1[e] = tsum; which = 1; pk0 = e; }
+      else if (i < S_PAD) { e = i - S_DB2; k.db2[e] = tsum; which = 3; pk0 = 16 + e; }
+      else if (i < S_DW1) {}
+      else if (i < S_DW2) {
+        e = i - S_DW1; k.dw1[e] = tsum; which = 0;
+        pk0 = (e >> 5) * W1K + ((e >> 2) & 3) * 8 + (e & 3) * 2 + ((e >> 4) & 1);          // [o][kh*8 + kw*2 + ci]
+      } else if (i < S_DWFC) {
+        e = i - S_DW2; k.dw2[e] = tsum; which = 2;
+        const int o = e >> 8, ci = (e >> 4) & 15, kh = (e >> 2) & 3, kw = e & 3;
+        pk0 = 16 * W1K + o * W2FK + (kh * 4 + kw) * 16 + ci;                                 // forward image
+        pk1 = 16 * W1K + 32 * W2FK + (((kh & 1) * 2 + (kw & 1)) * 16 + ci) * W2BK + ((kh >> 1) * 2 + (kw >> 1)) * 32 + o;
+      } else {                                     // slab: k' = pix*32 + c   ->   torch: c*P + pix
         const int kp = i - S_DWFC, P = OH2 * d.OW2;
-        if (kp < d.KFC) k.dwfc[(kp & 31) * P + (kp >> 5)] = tsum;
+        if (kp < d.KFC) { e = (kp & 31) * P + (kp >> 5); k.dwfc[e] = tsum; which = 4; pk0 = W_ELEMS + kp; }
+      }
+      if constexpr (FINISH == 2) {
+        if (which >= 0) {
+          const float w1 = 1.0f - u.hyper[2], beta2 = u.hyper[3], omb2 = 1.0f - u.hyper[3], eps = u.hyper[4];
+          const float step_size = hy[0], bc2_sqrt = hy[1];
+          float* pp = u.p[which] + e; float* pm = u.m[which] + e; float* pv = u.v[which] + e;
+          float pn = *pp, mj = *pm, vj = *pv;
+          adam_element(pn, mj, vj, tsum, u.hyper[5], w1, beta2, omb2, eps, step_size, bc2_sqrt);
+          *pp = pn; *pm = mj; *pv = vj;
+          if (which & 1) ((float*)(u.pack + total))[pk0] = pn;               // biases: fp32 tail of the pack
+          else {
+            u.pack[pk0] = (__bf16)pn;
+            if (pk1 >= 0) u.pack[pk1] = (__bf16)pn;
+          }
+        }
+      }
+    }
+  }
+  if constexpr (FINISH == 2) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (atomicAdd(u.done, 1) == (int)(gridDim.x * gridDim.y) - 1) {
+        u.hyper[0] = __int_as_float(__float_as_int(u.hyper[0]) + 1);
+        u.hyper[6] = hy[0];
+        u.hyper[7] = hy[1];
+        *u.done = 0;
       }
     }
   }
@@ -681,10 +737,10 @@ extern "C" size_t gdm_dcnn_fused_workspace_bytes(int B, int T, int want_grad) {
   return (size_t)(n_blocks(B) + 65) * slab_width(d, want_grad) * sizeof(float);
 }
 
-extern "C" int gdm_dcnn_fused(const float* xa, int bsplit, const float* p0, const float* p1, int B, int T, float ya,
-                              float yb, const void* pack, float* logits, float* loss, int accumulate_loss,
-                              int want_grad, float* dw1, float* db1, float* dw2, float* db2, float* dwfc, float* dbfc,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+static int dcnn_fused_impl(const float* xa, int bsplit, const float* p0, const float* p1, int B, int T, float ya,
+                           float yb, const void* pack, float* logits, float* loss, int accumulate_loss,
+                           int want_grad, float* dw1, float* db1, float* dw2, float* db2, float* dwfc, float* dbfc,
+                           const DcnnUpdate* upd, void* workspace, size_t workspace_bytes, void* stream) {
   GDM_REQUIRE(pack && logits && loss && B > 0, "gdm_dcnn_fused: null pointer / empty batch");
   GDM_REQUIRE(supported(T), "gdm_dcnn_fused: roll length T=%d is outside the fused kernel's range", T);
   GDM_REQUIRE(bsplit >= 0 && bsplit <= B && (bsplit == 0 || xa) && (bsplit == B || (p0 && p1)),
@@ -715,8 +771,38 @@ extern "C" int gdm_dcnn_fused(const float* xa, int bsplit, const float* p0, cons
   // dependent launches for the same 14-21 MB of reads
   const unsigned gx = (unsigned)((width + 63) / 64);
   const DcnnSinks sinks{loss, accumulate_loss, want_grad, dw1, db1, dw2, db2, dwfc, dbfc, T};
-  hipLaunchKernelGGL(dcnn_slab_sum<true>, dim3(gx, 1), dim3(1024), 0, s, (const float*)slabs, nb, nb, width,
-                     (float*)nullptr, sinks);
+  if (upd) {
+    hipLaunchKernelGGL(dcnn_slab_sum<2>, dim3(gx, 1), dim3(1024), 0, s, (const float*)slabs, nb, nb, width,
+                       (float*)nullptr, sinks, *upd);
+  } else {
+    hipLaunchKernelGGL(dcnn_slab_sum<1>, dim3(gx, 1), dim3(1024), 0, s, (const float*)slabs, nb, nb, width,
+                       (float*)nullptr, sinks, DcnnUpdate{});
+  }
   GDM_LAUNCH_OK("gdm_dcnn_fused");
   return GDM_OK;
+}
+
+extern "C" int gdm_dcnn_fused(const float* xa, int bsplit, const float* p0, const float* p1, int B, int T, float ya,
+                              float yb, const void* pack, float* logits, float* loss, int accumulate_loss,
+                              int want_grad, float* dw1, float* db1, float* dw2, float* db2, float* dwfc, float* dbfc,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  return dcnn_fused_impl(xa, bsplit, p0, p1, B, T, ya, yb, pack, logits, loss, accumulate_loss, want_grad, dw1, db1, dw2,
+                         db2, dwfc, dbfc, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int gdm_dcnn_fused_adam(const float* xa, int bsplit, const float* p0, const float* p1, int B, int T, float ya,
+                                   float yb, void* pack, float* logits, float* loss, int accumulate_loss, float* dw1,
+                                   float* db1, float* dw2, float* db2, float* dwfc, float* dbfc,
+                                   const gdm_dcnn_adam* opt, void* workspace, size_t workspace_bytes, void* stream) {
+  GDM_REQUIRE(opt && opt->hyper && opt->done, "gdm_dcnn_fused_adam: optimizer record missing");
+  DcnnUpdate u{};
+  for (int q = 0; q < 6; ++q) {
+    GDM_REQUIRE(opt->param[q] && opt->exp_avg[q] && opt->exp_avg_sq[q], "gdm_dcnn_fused_adam: null optimizer tensor %d", q);
+    u.p[q] = opt->param[q]; u.m[q] = opt->exp_avg[q]; u.v[q] = opt->exp_avg_sq[q];
+  }
+  u.hyper = opt->hyper;
+  u.done = opt->done;
+  u.pack = (__bf16*)pack;
+  return dcnn_fused_impl(xa, bsplit, p0, p1, B, T, ya, yb, pack, logits, loss, accumulate_loss, 1, dw1, db1, dw2, db2,
+                         dwfc, dbfc, &u, workspace, workspace_bytes, stream);
 }

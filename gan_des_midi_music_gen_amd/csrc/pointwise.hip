@@ -45,26 +45,16 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
             vv = *(const f32x4*)(v + i);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float gj = gg[j] * gscale;
-        const float mj = (w1 < 0.5f) ? mm[j] + w1 * (gj - mm[j]) : gj - (gj - mm[j]) * (1.f - w1);
-        const float vj = vv[j] * beta2 + one_minus_b2 * gj * gj;
-        const float denom = sqrtf(vj) / bc2_sqrt + eps;
-        pp[j] = pp[j] - step_size * (mj / denom);
-        mm[j] = mj;
-        vv[j] = vj;
+        float pj = pp[j], mj = mm[j], vj = vv[j];
+        adam_element(pj, mj, vj, gg[j], gscale, w1, beta2, one_minus_b2, eps, step_size, bc2_sqrt);
+        pp[j] = pj; mm[j] = mj; vv[j] = vj;
       }
       *(f32x4*)(p + i) = pp;
       *(f32x4*)(m + i) = mm;
       *(f32x4*)(v + i) = vv;
     } else {
       for (int64_t k = i; k < n && k < i + 4; ++k) {
-        const float gj = g[k] * gscale;
-        const float mj = (w1 < 0.5f) ? m[k] + w1 * (gj - m[k]) : gj - (gj - m[k]) * (1.f - w1);
-        const float vj = v[k] * beta2 + one_minus_b2 * gj * gj;
-        const float denom = sqrtf(vj) / bc2_sqrt + eps;
-        p[k] = p[k] - step_size * (mj / denom);
-        m[k] = mj;
-        v[k] = vj;
+        adam_element(p[k], m[k], v[k], g[k], gscale, w1, beta2, one_minus_b2, eps, step_size, bc2_sqrt);
       }
     }
   }
@@ -130,13 +120,9 @@ __global__ __launch_bounds__(256) void adam_dev_pc_kernel(float* __restrict__ p,
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float gj = gg[e] * gscale;
-      const float mj = (w1 < 0.5f) ? mv[e] + w1 * (gj - mv[e]) : gj - (gj - mv[e]) * (1.f - w1);
-      const float vj = vv[e] * beta2 + omb2 * gj * gj;
-      const float denom = sqrtf(vj) / bc2_sqrt + eps;
-      pv[e] = pv[e] - step_size * (mj / denom);
-      mv[e] = mj;
-      vv[e] = vj;
+      float pj = pv[e], mj = mv[e], vj = vv[e];
+      adam_element(pj, mj, vj, gg[e], gscale, w1, beta2, omb2, eps, step_size, bc2_sqrt);
+      pv[e] = pj; mv[e] = mj; vv[e] = vj;
     }
     if (full) {
 #ifndef GDM_ADAM_DEFAULT_POLICY       /* p, m, v are read once and written once per step: non-temporal */
@@ -173,26 +159,16 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
             vv = *(const f32x4*)(v + i);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float gj = gg[j] * gscale;
-        const float mj = (w1 < 0.5f) ? mm[j] + w1 * (gj - mm[j]) : gj - (gj - mm[j]) * (1.f - w1);
-        const float vj = vv[j] * beta2 + omb2 * gj * gj;
-        const float denom = sqrtf(vj) / bc2_sqrt + eps;
-        pp[j] = pp[j] - step_size * (mj / denom);
-        mm[j] = mj;
-        vv[j] = vj;
+        float pj = pp[j], mj = mm[j], vj = vv[j];
+        adam_element(pj, mj, vj, gg[j], gscale, w1, beta2, omb2, eps, step_size, bc2_sqrt);
+        pp[j] = pj; mm[j] = mj; vv[j] = vj;
       }
       *(f32x4*)(p + i) = pp;
       *(f32x4*)(m + i) = mm;
       *(f32x4*)(v + i) = vv;
     } else {
       for (int64_t k = i; k < n && k < i + 4; ++k) {
-        const float gj = g[k] * gscale;
-        const float mj = (w1 < 0.5f) ? m[k] + w1 * (gj - m[k]) : gj - (gj - m[k]) * (1.f - w1);
-        const float vj = v[k] * beta2 + omb2 * gj * gj;
-        const float denom = sqrtf(vj) / bc2_sqrt + eps;
-        p[k] = p[k] - step_size * (mj / denom);
-        m[k] = mj;
-        v[k] = vj;
+        adam_element(p[k], m[k], v[k], g[k], gscale, w1, beta2, omb2, eps, step_size, bc2_sqrt);
       }
     }
   }

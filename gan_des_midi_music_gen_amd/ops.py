@@ -636,11 +636,14 @@ def dcnn_pack(w1, b1, w2, b2, wfc, bfc, t, out=None):
     return pack
 
 
-def dcnn_fused(xa, planes, t, ya, yb, pack, *, loss_out, accumulate_loss=False, want_grad=True, grad_out=None):
+def dcnn_fused(xa, planes, t, ya, yb, pack, *, loss_out, accumulate_loss=False, want_grad=True, grad_out=None,
+               adam=None):
     """DiscriminatorCNN forward + BCE loss (+ backward) in one persistent kernel.
 
     xa: (Ba,2,128,T) fp32 contiguous or None (label ya); planes: (p0, p1) each (Bb,128,T) or None (label yb).
-    grad_out: 6 tensors (dw1, db1, dw2, db2, dwfc, dbfc) to fill.  Returns (logits (B,), grads or None)."""
+    grad_out: 6 tensors (dw1, db1, dw2, db2, dwfc, dbfc) to fill.  Returns (logits (B,), grads or None).
+    adam = dict(params=[6 tensors], exp_avg=[6], exp_avg_sq=[6], hyper=(8,) fp32, done=(1,) int32): the optimizer step
+    and the refresh of ``pack`` ride the gradient's final summation (gdm_dcnn_fused_adam; one rank only)."""
     _need_gpu(xa, pack, loss_out)
     ba = 0 if xa is None else xa.shape[0]
     p0 = p1 = None
@@ -670,6 +673,23 @@ def dcnn_fused(xa, planes, t, ya, yb, pack, *, loss_out, accumulate_loss=False, 
     nb = lib.gdm_dcnn_fused_workspace_bytes(b, int(t), 1 if want_grad else 0)
     ws = workspace(nb, dev)
     gp = [_p(g) for g in grads] if grads else [None] * 6
+    if adam is not None:
+        assert want_grad, "the fused optimizer step needs the gradient"
+        rec = _lib.DcnnAdam()
+        for field, key in (("param", "params"), ("exp_avg", "exp_avg"), ("exp_avg_sq", "exp_avg_sq")):
+            ts = adam[key]
+            assert len(ts) == 6
+            for i, (tq, g) in enumerate(zip(ts, grads)):
+                _need_gpu(tq)
+                assert tq.is_contiguous() and tq.dtype == torch.float32 and tq.numel() == g.numel(), (field, i)
+                getattr(rec, field)[i] = tq.data_ptr()
+        hyper, done = adam["hyper"], adam["done"]
+        _need_gpu(hyper, done)
+        assert hyper.numel() == 8 and hyper.dtype == torch.float32 and done.numel() == 1 and done.dtype == torch.int32
+        rec.hyper, rec.done = hyper.data_ptr(), done.data_ptr()
+        _call("gdm_dcnn_fused_adam", _p(xa), ba, _p(p0), _p(p1), b, int(t), float(ya), float(yb), _p(pack), _p(logits),
+              _p(loss_out), 1 if accumulate_loss else 0, *gp, ctypes.byref(rec), _p(ws), nb, _stream())
+        return logits, grads
     _call("gdm_dcnn_fused", _p(xa), ba, _p(p0), _p(p1), b, int(t), float(ya), float(yb), _p(pack), _p(logits),
           _p(loss_out), 1 if accumulate_loss else 0, 1 if want_grad else 0, *gp, _p(ws), nb, _stream())
     return logits, grads

@@ -703,8 +703,9 @@ class MmganTrainer(_TrainerBase):
     """
 
     def __init__(self, mmgan, lr=0.01, betas=(0.9, 0.999), eps=1e-8, compute_dtype=None, elide_dead_backward=False,
-                 process_group=None):
+                 process_group=None, fuse_optimizer=True):
         self.mm = mmgan
+        self.fuse_optimizer = fuse_optimizer      # one rank, fused bf16 path: Adam + re-pack inside the gradient's slab sum
         d = mmgan.discriminator
         self._init_common([d.conv1.weight, d.conv1.bias, d.conv2.weight, d.conv2.bias, d.fc.weight, d.fc.bias], lr,
                           betas, eps, compute_dtype, elide_dead_backward, process_group)
@@ -765,6 +766,27 @@ class MmganTrainer(_TrainerBase):
 
     def _fused_ok(self, t):
         return self.dt == ops.BF16 and ops.dcnn_fused_supported(t)
+
+    def _fused_adam_record(self):
+        """What ops.dcnn_fused needs to apply Adam itself (one rank): per-parameter views of the flat parameter / moment
+        buffers, the device hyper-parameter record (brought up to date; its step counter is advanced by the kernel) and
+        the finished-workgroups counter.  None with more than one rank (the gradient is exchanged first)."""
+        self._adam_in_kernel = self.world == 1 and self.fuse_optimizer
+        if not self._adam_in_kernel:
+            return None
+        d = self.d
+        want = d.sync_hyper(self.lr, self.betas, self.eps, 1.0)
+        if d._hyper is None:
+            d._hyper = ops.adam_hyper(d.flat.device, *want, step=d.step_count)
+            d._hyper_host = want
+        if getattr(self, "_adam_views", None) is None:
+            offs = [((v.data_ptr() - d.flat.data_ptr()) // 4, v.numel()) for v in d.views]
+            self._adam_views = ([d.flat[o:o + n] for o, n in offs], [d.exp_avg[o:o + n] for o, n in offs],
+                                [d.exp_avg_sq[o:o + n] for o, n in offs])
+            self._adam_done = torch.zeros(1, dtype=torch.int32, device=d.flat.device)
+        d.step_count += 1
+        p, m, v = self._adam_views
+        return dict(params=p, exp_avg=m, exp_avg_sq=v, hyper=d._hyper, done=self._adam_done)
 
     def _gen_fused_ok(self, b):
         """Whether an iteration's generator work takes the fused chain (staged inputs + one launch per block depth)."""
@@ -888,9 +910,11 @@ class MmganTrainer(_TrainerBase):
                 self._pack = ops.dcnn_pack(w1, b1, w2, b2, wf, bf, t)
                 self._pack_t = t
             fa = Fn._f32c(fake_a)
-            # batch [fake ; real] with labels 0 / 1 (304-305); real_data is read as two planes: no stack/permute copy
+            # batch [fake ; real] with labels 0 / 1 (304-305); real_data is read as two planes: no stack/permute copy.
+            # One rank: disc_opt.step() (308) and the refresh of the packed weights ride the gradient's final summation
+            # (slab sum -> adam_prep -> Adam -> re-pack were four launches on the iteration's critical chain).
             ops.dcnn_fused(fa, (Fn._f32c(piano_roll), Fn._f32c(durations)), t, 0.0, 1.0, self._pack,
-                           loss_out=self.loss_d, grad_out=gv)
+                           loss_out=self.loss_d, grad_out=gv, adam=self._fused_adam_record())
             if gen_late:
                 generators()
         else:
@@ -923,9 +947,10 @@ class MmganTrainer(_TrainerBase):
         gv = self.d.grad_views
         t = piano_roll.shape[2]
         fused = self._fused_ok(t)
-        self._adam()
-        if fused:
-            ops.dcnn_pack(w1, b1, w2, b2, wf, bf, t, out=self._pack)     # weights changed: refresh in place
+        if not (fused and getattr(self, "_adam_in_kernel", False)):      # (else: already applied by _part_a's kernel)
+            self._adam()
+            if fused:
+                ops.dcnn_pack(w1, b1, w2, b2, wf, bf, t, out=self._pack)     # weights changed: refresh in place
         if callable(fake_b):
             if getattr(self, "_gen_join_pending", False):
                 # mixed bridge (tensor fake_a, callable fake_b): the generator chains were forked late and are still

@@ -257,6 +257,22 @@ int gdm_dcnn_fused(const float* xa, int bsplit, const float* p0, const float* p1
                    const void* pack, float* logits, float* loss, int accumulate_loss, int want_grad, float* dw1,
                    float* db1, float* dw2, float* db2, float* dwfc, float* dbfc, void* workspace,
                    size_t workspace_bytes, void* stream);
+/* The same pass with the optimizer step fused into the gradient's final summation (one rank: nothing to exchange between
+ * gradient and update): disc_opt.step() (network_tests.py:308, torch.optim.Adam) is applied by the threads that finish
+ * the gradient elements, and the updated weights are written straight into `pack` (in place: the next launch reads
+ * them).  param / exp_avg / exp_avg_sq: w1, b1, w2, b2, wfc, bfc; hyper = the 8-float device record of
+ * gdm_adam_step_dev (its step counter is advanced); done = one device int, zero before the first launch. */
+typedef struct gdm_dcnn_adam {
+  float* param[6];
+  float* exp_avg[6];
+  float* exp_avg_sq[6];
+  float* hyper;
+  int* done;
+} gdm_dcnn_adam;
+int gdm_dcnn_fused_adam(const float* xa, int bsplit, const float* p0, const float* p1, int B, int T, float ya, float yb,
+                        void* pack, float* logits, float* loss, int accumulate_loss, float* dw1, float* db1, float* dw2,
+                        float* db2, float* dwfc, float* dbfc, const gdm_dcnn_adam* opt, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* ---- generic convolution lowering helpers (model 2 discriminator, model 1 generator) ----------------------------
  * im2col for Conv2d fwd / dW and col2im (gather form, deterministic) for Conv2d dX and ConvTranspose2d fwd.

@@ -505,3 +505,33 @@ def test_replay_follows_the_lr_schedule():
         outs.append((tr.disc_loss_value(), mm.discriminator.fc.weight.detach().clone(),
                      mm.discriminator.conv1.weight.detach().clone()))
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_optimizer_step_inside_the_slab_sum_equals_separate_launches():
+    """One rank, fused bf16 path: disc_opt.step() (network_tests.py:308) and the refresh of the packed weight images ride
+    the final summation of the gradient (gdm_dcnn_fused_adam) instead of slab sum -> adam_prep -> Adam -> re-pack.  Same
+    arithmetic: parameters, Adam moments, packed images, losses and the device step counter are bit-identical to the
+    four-launch chain over several iterations with changing learning rate."""
+    b = 24
+    runs = []
+    for fuse in (True, False):
+        mm = _mm(21).to(DEV)
+        tr = MmganTrainer(mm, lr=0.01, compute_dtype="bf16", fuse_optimizer=fuse)
+        sched = StepLR(tr, step_size=2, gamma=0.5)
+        losses = []
+        for it in range(5):
+            d = synthetic.mmgan_inputs(b, 50, seed=600 + it, device=DEV)
+            dl, gl = tr.step(d["piano_roll"], d["durations"], d["beats"], d["noise1"], d["noise2"], d["fake_a"],
+                             d["fake_b"], g1_in_a=d["g1_in_a"], g1_in_b=d["g1_in_b"])
+            losses.append((dl.item(), gl.item()))
+            sched.step()
+        torch.cuda.synchronize()
+        assert getattr(tr, "_adam_in_kernel", False) == fuse
+        runs.append((losses, tr.d.flat.clone(), tr.d.exp_avg.clone(), tr.d.exp_avg_sq.clone(),
+                     tr._pack[:-16].clone(),            # (the last 16 bytes are alignment padding nobody writes)
+                     int(tr.d._hyper.view(torch.int32)[0].item()), tr.d.step_count))
+    a, c = runs
+    assert a[0] == c[0], (a[0], c[0])
+    for k in range(1, 5):
+        assert torch.equal(a[k], c[k]), k
+    assert a[5] == c[5] == 5 and a[6] == c[6] == 5
