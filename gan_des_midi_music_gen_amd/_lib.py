@@ -93,6 +93,7 @@ SIGNATURES = {
     "gdm_permute_pc": (_I, [_P, _I, _I, _I, _I, _P, _I, _P]),
     "gdm_des_scan": (_I, [_P, _L, _I, _I, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "gdm_des_routing": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _P]),
+    "gdm_des_run": (_I, [_P, _I, _P, _P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _L, _P, _P]),
     "gdm_piano_roll_raster": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "gdm_maxpool2_fwd": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "gdm_maxpool2_bwd": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P]),

@@ -274,6 +274,27 @@ int gdm_dcnn_fused_adam(const float* xa, int bsplit, const float* p0, const floa
                         float* db2, float* dwfc, float* dbfc, const gdm_dcnn_adam* opt, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* ---- deterministic discrete-event simulator core (host code; SIMULATOR/simulation_v3.py:25-74, 426-743) -------------
+ * One run of Sim(adj, distributions, queue_list, seeds=[seed], logging_mode='Music').run(number_of_customers) for 'normal'
+ * distributions (loc[i], scale[i] per node; what both bridges construct, matrix_sim_process.py:72-74 / 50-54) and
+ * probability routing.  adj (dim,dim) row-major float64: diagonal > 0 marks a source, <= 0 a server; queue_cap[i] =
+ * queue_list[i].  The per-node generators are numpy legacy RandomStates seeded from RandomState(seed).randint(3, 9999999)
+ * like the reference's; routing draws come from the GLOBAL numpy stream, whose state travels in and out through
+ * mt_key[624] / mt_pos / has_gauss / cached_gauss (np.random.get_state() / set_state()).  The run ends when the event
+ * list is empty, when number_of_customers customers have been generated (stop_reason 1), or after max_events processed
+ * events (stop_reason 2; the reference stops on a wall-clock limit instead, simulation_v3.py:496-499; 0 = no cap).
+ * out[0..n_out) = the 'Music' log records in order: kind 0 arrival / 1 departure (value = clock), 2 processing (value =
+ * service time).  GDM_EWORKSPACE when out_capacity is too small (n_out then holds the count needed). */
+typedef struct gdm_des_event {
+  double value;
+  int64_t event_id;
+  int32_t node;
+  int32_t kind;
+} gdm_des_event;
+int gdm_des_run(const double* adj, int dim, const double* loc, const double* scale, const int32_t* queue_cap, int64_t seed,
+                int64_t number_of_customers, int64_t max_events, uint32_t* mt_key, int* mt_pos, int* has_gauss,
+                double* cached_gauss, gdm_des_event* out, int64_t out_capacity, int64_t* n_out, int* stop_reason);
+
 /* ---- generic convolution lowering helpers (model 2 discriminator, model 1 generator) ----------------------------
  * im2col for Conv2d fwd / dW and col2im (gather form, deterministic) for Conv2d dX and ConvTranspose2d fwd.
  * Activations are channels-last (B,H,W,C) unless `src_planar` (NCHW fp32 input planes, e.g. the piano-roll).

@@ -26,11 +26,12 @@ What is stored (inputs AND expected outputs, all small):
   des_prologue.npz    what matrix_to_midi / matrix_to_wav hand to the DES: the reference functions are run with
                       `Sim` replaced by a recorder (constructor arguments captured, nothing simulated) under
                       np.random.seed(...); see des_prologue() below
+  des_core.npz        the reference's Sim itself ('Music' log records) on bridge-shaped arguments; see des_core()
   des_prologue_rng.npz  the same with a recorder whose run() DRAWS from numpy's global stream like Sim does: pins the
                       per-sample interleaving of prologue draws and simulation draws; see des_prologue_rng()
 
 `python tests/golden/make_golden.py` regenerates everything; `python tests/golden/make_golden.py NAME...` only the
-named sections (base, input_grads, simnn_net, des_prologue, des_prologue_rng).
+named sections (base, input_grads, simnn_net, des_prologue, des_prologue_rng, des_core).
 """
 import hashlib
 import importlib
@@ -339,6 +340,88 @@ def des_prologue_rng():
     np.savez_compressed(os.path.join(HERE, "des_prologue_rng.npz"), **out)
 
 
+
+def des_core():
+    """des_core.npz: the reference's own ``Sim`` (SIMULATOR/simulation_v3.py, loaded from MMGAN_MIDI_DES/) run on the
+    constructor arguments the two bridges produce (specs from oracle/des_prologue.py, itself pinned by
+    des_prologue.npz), in 'Music' logging mode with a generous wall-clock limit (the runs end on number_of_customers,
+    never on the clock): every log record (value, event id, node, kind), and the position of numpy's global stream
+    afterwards -- Sim's routing draws come from it (simulation_v3.py:57,62).  The reference writes the records through
+    ``logging`` into logs/simulation.log (and, since Python 3.10, only the first Sim of a process gets a file handler:
+    the root logger's handlers are cleared before every run here)."""
+    import logging
+    import re
+    import tempfile
+    from oracle import des_prologue as odp
+    S = load_reference("MMGAN_MIDI_DES", "simulation_v3")
+    line_re = re.compile(r"INFO:root:(\S+) - (\S+) - (\S+) - (arrival|departure|processing)")
+    kinds = {"arrival": 0, "departure": 1, "processing": 2}
+    out = {}
+
+    def run_case(pre, spec, customers):
+        cwd = os.getcwd()
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            os.makedirs("logs")
+            try:
+                for h in list(logging.root.handlers):
+                    logging.root.removeHandler(h)
+                sim = S.Sim(spec["sim_matrix"], spec["distributions"], spec["queue_list"], seeds=spec["seeds"],
+                            log_path="logs/", generate_log=True, animation=False, record_history=False,
+                            logging_mode='Music', max_sim_time=1e9)
+                sim.run(number_of_customers=customers)
+                rows = []
+                for ln in open("logs/simulation.log"):
+                    m = line_re.match(ln.strip())
+                    assert m, ln
+                    rows.append((float(m.group(1)), int(m.group(2)), int(m.group(3)), kinds[m.group(4)]))
+            finally:
+                os.chdir(cwd)
+        out[f"{pre}/sim_matrix"] = np.asarray(spec["sim_matrix"], dtype=np.float64)
+        out[f"{pre}/dist"] = np.array([[float(d[1]), float(d[2])] for d in spec["distributions"]], dtype=np.float64)
+        out[f"{pre}/queue_list"] = np.array(spec["queue_list"])
+        out[f"{pre}/seeds"] = np.asarray(spec["seeds"])
+        out[f"{pre}/customers"] = np.int64(customers)
+        out[f"{pre}/value"] = np.array([r[0] for r in rows], dtype=np.float64)
+        out[f"{pre}/event_id"] = np.array([r[1] for r in rows], dtype=np.int64)
+        out[f"{pre}/node"] = np.array([r[2] for r in rows], dtype=np.int32)
+        out[f"{pre}/kind"] = np.array([r[3] for r in rows], dtype=np.int32)
+        out[f"{pre}/rng_after"] = np.int64(np.random.randint(0, 2 ** 31 - 1))
+        assert len(rows) > 50, (pre, len(rows))
+
+    # model 2's bridge: 64x64 generator output -> 61 nodes; the prologue's draws and Sim's draws share np.random
+    m, g2 = _des_inputs(2, 64, 20, 700)
+    np.random.seed(99)
+    for i, spec in enumerate(odp.midi_prologue(m[:, None], g2, adj_size=(64, 64))):
+        pass                                              # (draws of both samples first: specs only)
+    specs = odp.midi_prologue(m[:, None], g2, adj_size=(64, 64))
+    for i, (spec, customers) in enumerate(zip(specs, (400, 1500))):
+        np.random.seed(1000 + i)
+        run_case(f"midi{i}", spec, customers)
+    # model 1's bridge: 20x20 -> 15 nodes, 1000 customers (GAN_DES/matrix_sim_process.py:108-110)
+    mw, _ = _des_inputs(2, 20, 1, 800)
+    mw[:, 15, :] = np.minimum(np.abs(mw[:, 15, :]), 0.7)
+    np.random.seed(5)
+    for i, spec in enumerate(odp.wav_prologue(mw, size=20)):
+        np.random.seed(2000 + i)
+        run_case(f"wav{i}", spec, 1000 if i == 0 else 120)
+    # a hand-made network with a node whose only destination is node 0 ("sink" by sum(children) == 0), a zero-variance
+    # service time, and several sources feeding one server with a short queue (reneging)
+    adj = np.zeros((5, 5))
+    adj[0, 0], adj[0, 1] = -1.0, 1.0
+    adj[1, 1], adj[1, 2], adj[1, 0] = -1.0, 0.5, 0.5
+    adj[2, 2], adj[2, 0] = -1.0, 1.0
+    adj[3, 3], adj[3, 1] = 1.0, 1.0
+    adj[4, 4], adj[4, 1] = 1.0, 1.0
+    spec = {"sim_matrix": adj, "distributions": [["normal", np.float32(0.4), np.float32(0.1)], ["normal", np.float32(0.9), np.float32(0.5)],
+                                                  ["normal", np.float32(0.25), np.float32(0.0)], ["normal", np.float32(1.0), np.float32(0.3)],
+                                                  ["normal", np.float32(0.7), np.float32(0.6)]],
+            "queue_list": [3, 2, 4, 1, 1], "seeds": np.array([4242])}
+    np.random.seed(77)
+    run_case("hand", spec, 200)
+    np.savez_compressed(os.path.join(HERE, "des_core.npz"), **out)
+
+
 def main():
     torch.set_num_threads(4)
     from gan_des_midi_music_gen_amd import synthetic
@@ -561,7 +644,7 @@ def main():
 
 
 SECTIONS = {"base": main, "input_grads": input_grads, "simnn_net": simnn_net, "des_prologue": des_prologue,
-            "des_prologue_rng": des_prologue_rng}
+            "des_prologue_rng": des_prologue_rng, "des_core": des_core}
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
