@@ -75,6 +75,7 @@ SIGNATURES = {
     "gdm_simnn_conv1_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I]),
     "gdm_simnn_conv1_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _I, _P, _Z, _P]),
     "gdm_simnn_conv1_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "gdm_simnn_adam_step": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P]),
     "gdm_simnn_head_workspace_bytes": (_Z, [_I]),
     "gdm_simnn_head": (_I, [_P, _P, _P, _I, _I, _F, _F, _P, _P, _I, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "gdm_linear_bn_act_max_rows": (_I, []),

@@ -2,6 +2,7 @@
 // batch norm + activation (forward/backward), bias+activation, column sums, casts.
 // All reductions are fixed-order (no float atomics) so a training run is bit-reproducible on one device.
 #include "gdm_common.h"
+#include "adam_pc.h"
 
 namespace {
 
@@ -66,10 +67,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 __global__ void adam_prep_kernel(float* __restrict__ hyper) {
   int step = __float_as_int(hyper[0]) + 1;
   hyper[0] = __int_as_float(step);
-  const double b1 = (double)hyper[2], b2 = (double)hyper[3];
-  const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
-  hyper[6] = (float)((double)hyper[1] / bc1);
-  hyper[7] = (float)sqrt(bc2);
+  float ss, bq;
+  adam_derived(hyper, step, ss, bq);
+  hyper[6] = ss;
+  hyper[7] = bq;
 }
 
 // Adam on a parameter whose GRADIENT arrives in the channels-last ("permuted") layout and whose updated value is also
@@ -87,63 +88,8 @@ __global__ __launch_bounds__(256) void adam_dev_pc_kernel(float* __restrict__ p,
                                                           TS* __restrict__ shadow_pc,
                                                           const float* __restrict__ hyper, int vec_ok) {
   __shared__ __attribute__((aligned(16))) float tile[32][132];        // [c][p], rows 16-byte aligned
-  const float w1 = 1.0f - hyper[2], beta2 = hyper[3], omb2 = 1.0f - hyper[3], eps = hyper[4], gscale = hyper[5];
-  const float step_size = hyper[6], bc2_sqrt = hyper[7];
-  const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
-  const int p0 = blockIdx.x * 128, c0 = blockIdx.y * 32, n = blockIdx.z;
-  const int64_t base = (int64_t)n * C * P;
-  const bool full = vec_ok && p0 + 128 <= P && c0 + 32 <= C;      // 16-byte accesses to p, m, v
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {                                     // gradient tile, read along c
-    const int pl = ty + 8 * i, pp = p0 + pl, c = c0 + tx;
-    tile[tx][pl] = (pp < P && c < C) ? g_pc[base + (int64_t)pp * C + c] : 0.f;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {                                      // p, m, v along p: four elements per thread
-    const int cl = ty + 8 * i, c = c0 + cl, pp = p0 + 4 * tx;
-    const int64_t k = base + (int64_t)c * P + pp;
-    f32x4 gg = *(const f32x4*)&tile[cl][4 * tx], pv, mv, vv;
-    if (full) {
-#ifndef GDM_ADAM_DEFAULT_POLICY       /* p, m, v are read once and written once per step: non-temporal */
-      pv = __builtin_nontemporal_load((const f32x4*)(p + k)); mv = __builtin_nontemporal_load((const f32x4*)(m + k));
-      vv = __builtin_nontemporal_load((const f32x4*)(v + k));
-#else
-      pv = *(const f32x4*)(p + k); mv = *(const f32x4*)(m + k); vv = *(const f32x4*)(v + k);
-#endif
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool ok = c < C && pp + e < P;
-        pv[e] = ok ? p[k + e] : 0.f; mv[e] = ok ? m[k + e] : 0.f; vv[e] = ok ? v[k + e] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float pj = pv[e], mj = mv[e], vj = vv[e];
-      adam_element(pj, mj, vj, gg[e], gscale, w1, beta2, omb2, eps, step_size, bc2_sqrt);
-      pv[e] = pj; mv[e] = mj; vv[e] = vj;
-    }
-    if (full) {
-#ifndef GDM_ADAM_DEFAULT_POLICY       /* p, m, v are read once and written once per step: non-temporal */
-      __builtin_nontemporal_store(pv, (f32x4*)(p + k)); __builtin_nontemporal_store(mv, (f32x4*)(m + k));
-      __builtin_nontemporal_store(vv, (f32x4*)(v + k));
-#else
-      *(f32x4*)(p + k) = pv; *(f32x4*)(m + k) = mv; *(f32x4*)(v + k) = vv;
-#endif
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (c < C && pp + e < P) { p[k + e] = pv[e]; m[k + e] = mv[e]; v[k + e] = vv[e]; }
-    }
-    *(f32x4*)&tile[cl][4 * tx] = pv;                                  // the elements this thread read: no hazard
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {                                     // updated weight, written along c
-    const int pl = ty + 8 * i, pp = p0 + pl, c = c0 + tx;
-    if (pp < P && c < C) shadow_pc[base + (int64_t)pp * C + c] = from_f32<TS>(tile[tx][pl]);
-  }
+  adam_pc_tile<TS>(tile, p, g_pc, m, v, C, P, shadow_pc, hyper, vec_ok, hyper[6], hyper[7], blockIdx.x, blockIdx.y,
+                   blockIdx.z);
 }
 
 template <bool VEC>

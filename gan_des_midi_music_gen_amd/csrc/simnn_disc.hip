@@ -14,6 +14,7 @@
 // T = __bf16: bf16 storage + v_mfma_f32_16x16x32_bf16, fp32 accumulation
 #include <cstdlib>
 #include "gdm_common.h"
+#include "adam_pc.h"
 
 namespace {
 
@@ -478,6 +479,56 @@ __global__ __launch_bounds__(256) void conv2_pack_kernel(const float* __restrict
     float v = 0.f;
     if (k < 288) v = w[((k & 31) * 16 + ci) * 9 + (8 - (k >> 5))];
     wb[i] = from_f32<T>(v);
+  }
+}
+
+// ---- the discriminator's whole optimizer step in ONE launch -------------------------------------------------------------
+// disc_opt.step() (GAN_DES/SIMNN.py:316) was adam_prep -> Adam(small parameters) -> Adam(fc1.weight, transposing) ->
+// conv2 re-pack: four launches at the end of the iteration's critical chain (~15 us of launch tails for 5 us of work).
+// Here the grid is fc1.weight's (p, c, n) tiles plus ONE more workgroup that updates the 4.9 k small parameters and then
+// rebuilds conv2's packed MFMA images from the weights it has just written; every workgroup derives the step's
+// bias-correction terms itself from the device record, and the last one to finish advances the record's step counter
+// (all of them have read it by then).  Same arithmetic (adam_element, adam_derived): bit-identical to the four launches.
+template <typename T>
+__global__ __launch_bounds__(256) void simnn_adam_kernel(float* __restrict__ p, const float* __restrict__ g_pc,
+                                                         float* __restrict__ m, float* __restrict__ v, int C, int P,
+                                                         T* __restrict__ shadow_pc, int vec_ok, int tiles_x, int tiles_y,
+                                                         int n_big_blocks, float* __restrict__ ps,
+                                                         const float* __restrict__ gs, float* __restrict__ ms,
+                                                         float* __restrict__ vs, int n_small,
+                                                         const float* __restrict__ w2, T* __restrict__ wf,
+                                                         T* __restrict__ wb, float* __restrict__ hyper,
+                                                         int* __restrict__ done) {
+  __shared__ __attribute__((aligned(16))) float tile[32][132];
+  __shared__ float hy[2];
+  const int step = __float_as_int(hyper[0]) + 1;
+  if (threadIdx.x == 0) adam_derived(hyper, step, hy[0], hy[1]);
+  __syncthreads();
+  const float step_size = hy[0], bc2_sqrt = hy[1];
+  const int blk = blockIdx.x;
+  if (blk < n_big_blocks) {
+    const int bx = blk % tiles_x, by = (blk / tiles_x) % tiles_y, bz = blk / (tiles_x * tiles_y);
+    adam_pc_tile<T>(tile, p, g_pc, m, v, C, P, shadow_pc, hyper, vec_ok, step_size, bc2_sqrt, bx, by, bz);
+  } else {
+    const float w1 = 1.0f - hyper[2], beta2 = hyper[3], omb2 = 1.0f - hyper[3], eps = hyper[4], gscale = hyper[5];
+    for (int i = threadIdx.x; i < n_small; i += 256)
+      adam_element(ps[i], ms[i], vs[i], gs[i], gscale, w1, beta2, omb2, eps, step_size, bc2_sqrt);
+    __syncthreads();                                       // conv2.weight (inside the small range) is up to date
+    for (int i = threadIdx.x; i < C2<T>::WF_ELEMS; i += 256) {
+      const int o = i / C2<T>::KPF, k = i % C2<T>::KPF;
+      wf[i] = from_f32<T>(k < 144 ? w2[(o * 16 + (k & 15)) * 9 + (k >> 4)] : 0.f);
+    }
+    for (int i = threadIdx.x; i < C2<T>::WB_ELEMS; i += 256) {
+      const int ci = i / C2<T>::KPB, k = i % C2<T>::KPB;
+      wb[i] = from_f32<T>(k < 288 ? w2[((k & 31) * 16 + ci) * 9 + (8 - (k >> 5))] : 0.f);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(done, 1) == (int)gridDim.x - 1) {
+    hyper[0] = __int_as_float(step);
+    hyper[6] = step_size;
+    hyper[7] = bc2_sqrt;
+    *done = 0;
   }
 }
 
@@ -1810,6 +1861,27 @@ extern "C" int gdm_simnn_conv2_pack(const float* w, int dtype, void* pack, void*
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv2_pack_kernel<T>, dim3((C2<T>::WF_ELEMS + 255) / 256), dim3(256), 0,
                                        (hipStream_t)stream, w, (T*)pack, (T*)pack + C2<T>::WF_ELEMS));
   GDM_LAUNCH_OK("gdm_simnn_conv2_pack");
+  return GDM_OK;
+}
+
+extern "C" int gdm_simnn_adam_step(float* p_big, const float* g_big_pc, float* m_big, float* v_big, int N, int C, int P,
+                                   void* shadow_pc, float* p_small, const float* g_small, float* m_small, float* v_small,
+                                   int n_small, const float* conv2_weight, void* pack, int dtype, float* hyper, int* done,
+                                   void* stream) {
+  GDM_REQUIRE(p_big && g_big_pc && m_big && v_big && shadow_pc && p_small && g_small && m_small && v_small && conv2_weight &&
+              pack && hyper && done, "gdm_simnn_adam_step: null pointer");
+  GDM_REQUIRE(N > 0 && C > 0 && P > 0 && n_small > 0 && gdm_dtype_ok(dtype), "gdm_simnn_adam_step: bad arguments");
+  GDM_REQUIRE(conv2_weight >= p_small && conv2_weight + 4608 <= p_small + n_small,
+              "gdm_simnn_adam_step: conv2.weight must lie inside the small-parameter range (it is re-packed from there)");
+  const int tx = (P + 127) / 128, ty = (C + 31) / 32;
+  const int64_t nbig = (int64_t)tx * ty * N;
+  GDM_REQUIRE(nbig < ((int64_t)1 << 30), "gdm_simnn_adam_step: parameter too large");
+  const int vec_ok = (P % 4 == 0) && ((((uintptr_t)p_big | (uintptr_t)m_big | (uintptr_t)v_big) & 15) == 0);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(simnn_adam_kernel<T>, dim3((unsigned)nbig + 1), dim3(256), 0, (hipStream_t)stream, p_big,
+                                       g_big_pc, m_big, v_big, C, P, (T*)shadow_pc, vec_ok, tx, ty, (int)nbig, p_small, g_small,
+                                       m_small, v_small, n_small, conv2_weight, (T*)pack, (T*)pack + C2<T>::WF_ELEMS, hyper,
+                                       done));
+  GDM_LAUNCH_OK("gdm_simnn_adam_step");
   return GDM_OK;
 }
 

@@ -200,6 +200,25 @@ def adam_step_dev_pc(p, g_pc, m, v, n, c, pix, shadow_pc, hyper, advance_step=Fa
           _p(hyper), 1 if advance_step else 0, _stream())
 
 
+def simnn_adam_step(p_big, g_big_pc, m_big, v_big, n, c, pix, shadow_pc, p_small, g_small, m_small, v_small, conv2_weight,
+                    pack, hyper, done):
+    """Model 1's whole discriminator optimizer step in one launch (gdm_simnn_adam_step): transposing Adam on the
+    (n, c, pix) parameter, plain Adam on the contiguous small range (which holds ``conv2_weight``), re-pack of conv2's
+    MFMA images into ``pack``; the device step counter in ``hyper`` is advanced."""
+    _need_gpu(p_big, g_big_pc, m_big, v_big, shadow_pc, p_small, g_small, m_small, v_small, conv2_weight, pack, hyper, done)
+    for t in (p_big, g_big_pc, m_big, v_big):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n * c * pix
+    for t in (p_small, g_small, m_small, v_small):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p_small.numel()
+    assert shadow_pc.is_contiguous() and shadow_pc.numel() == n * c * pix and conv2_weight.numel() == 4608
+    assert hyper.numel() == 8 and done.numel() == 1 and done.dtype == torch.int32
+    dt = gdm_dtype(shadow_pc)
+    assert pack.numel() == _lib.load().gdm_simnn_conv2_pack_bytes(dt)
+    _call("gdm_simnn_adam_step", _p(p_big), _p(g_big_pc), _p(m_big), _p(v_big), n, c, pix, _p(shadow_pc), _p(p_small),
+          _p(g_small), _p(m_small), _p(v_small), p_small.numel(), _p(conv2_weight), _p(pack), dt, _p(hyper), _p(done),
+          _stream())
+
+
 def bn_act_fwd(y, gamma, beta, running_mean, running_var, nbt, *, act, out_dtype=F32, training=True, momentum=0.1,
                eps=1e-5):
     """y (rows, C) fp32 -> (out, save_mean, save_invstd)."""

@@ -258,8 +258,9 @@ class SimnnTrainer(_TrainerBase):
     """
 
     def __init__(self, gen, disc, lr=0.00002, betas=(0.5, 0.999), eps=1e-8, compute_dtype=None,
-                 elide_dead_backward=False, process_group=None, overlap=True):
+                 elide_dead_backward=False, process_group=None, overlap=True, one_launch_optimizer=True):
         self.gen, self.disc = gen, disc
+        self.one_launch_optimizer = one_launch_optimizer     # False: adam_prep, Adam(small), Adam(fc1.weight), re-pack
         self._init_common([disc.conv1.weight, disc.conv1.bias, disc.conv2.weight, disc.conv2.bias, disc.fc1.weight,
                            disc.fc1.bias, disc.fc2.weight, disc.fc2.bias], lr, betas, eps, compute_dtype,
                           elide_dead_backward, process_group)
@@ -298,9 +299,23 @@ class SimnnTrainer(_TrainerBase):
         conv2's packed images are rebuilt right after."""
         wf1 = self.d.views[4]
         n, k = wf1.shape
-        self.d.adam(self.lr, self.betas, self.eps, grad_scale=1.0 / self.world,
-                    big_pc=(n, 32, k // 32, self._prepared[1]))
-        ops.simnn_conv2_pack(self.d.views[2], self.dt, out=self._prepared[0])
+        d = self.d
+        if not self.one_launch_optimizer:
+            d.adam(self.lr, self.betas, self.eps, grad_scale=1.0 / self.world, big_pc=(n, 32, k // 32, self._prepared[1]))
+            ops.simnn_conv2_pack(d.views[2], self.dt, out=self._prepared[0])
+            return
+        # one launch: adam_prep + Adam(small) + Adam(fc1.weight) + conv2 re-pack (gdm_simnn_adam_step)
+        want = d.sync_hyper(self.lr, self.betas, self.eps, 1.0 / self.world)
+        if d._hyper is None:
+            d._hyper = ops.adam_hyper(d.flat.device, *want, step=d.step_count)
+            d._hyper_host = want
+        if getattr(self, "_adam_done", None) is None:
+            self._adam_done = torch.zeros(1, dtype=torch.int32, device=d.flat.device)
+        d.step_count += 1
+        ns = d.n_small
+        ops.simnn_adam_step(d.flat[ns:], d.grad[ns:], d.exp_avg[ns:], d.exp_avg_sq[ns:], n, 32, k // 32, self._prepared[1],
+                            d.flat[:ns], d.grad[:ns], d.exp_avg[:ns], d.exp_avg_sq[:ns], d.views[2], self._prepared[0],
+                            d._hyper, self._adam_done)
 
     def _gen_state(self):
         g = self.gen

@@ -195,6 +195,17 @@ int gdm_simnn_conv1_bwd_weight(const void* dp1, const uint64_t* code1, const flo
 int gdm_simnn_conv1_bwd_data(const void* dp1, const uint64_t* code1, const float* w, int B, int H, int W, float* dx,
                              int dtype, void* stream);
 
+/* disc_opt.step() of model 1 (SIMNN.py:316) in ONE launch: Adam on fc1.weight with the two layout changes of
+ * gdm_adam_step_dev_pc (gradient and operand copy in (N,P,C) order) + Adam on the n_small remaining parameters (one
+ * contiguous range p_small / g_small / m_small / v_small that contains conv2.weight) + the rebuild of conv2's packed
+ * images (gdm_simnn_conv2_pack) from the updated weights.  hyper: the 8-float device record of gdm_adam_step_dev (its
+ * step counter is advanced); done: one device int, zero before the first launch.  Bit-identical to the sequence
+ * gdm_adam_step_dev(small) + gdm_adam_step_dev_pc(big) + gdm_simnn_conv2_pack. */
+int gdm_simnn_adam_step(float* p_big, const float* g_big_pc, float* m_big, float* v_big, int N, int C, int P,
+                        void* shadow_pc, float* p_small, const float* g_small, float* m_small, float* v_small,
+                        int n_small, const float* conv2_weight, void* pack, int dtype, float* hyper, int* done,
+                        void* stream);
+
 /* head of model 1's discriminator, forward + loss + backward in one launch (SIMNN.py:140-141, 289/311/329):
  * h1 (n,128) fp32 = relu(fc1) -> prob (n) = sigmoid(fc2), loss[0] (+)= sum over the two label halves of the batch
  * means of BCEWithLogits(prob, y) (rows [0,n0) label y0, rows [n0,n) label y1; the sigmoid OUTPUT is fed to the

@@ -94,3 +94,33 @@ def test_melspectrogram_batch_silence_and_errors():
         util.get_melspectrogram_db_tensor(torch.zeros(5 * SR))                          # CPU tensor: no fallback
     with pytest.raises(ops.GdmError):
         util.melspectrogram_db_batch(torch.zeros(1, 600).cuda(), hop=100)               # shorter than the reflect pad
+
+
+def _read_wav(path):
+    """What torchaudio.load(path, normalize=True) returns for 16-bit PCM: (channels, frames) float32 in [-1, 1), rate."""
+    import wave
+    with wave.open(path) as w:
+        assert w.getsampwidth() == 2
+        raw = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, w.getnchannels())
+        return (raw.T.astype(np.float32) / 32768.0), w.getframerate()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["simulation.wav", "generation_first5s.wav", "output_0_first5s.wav"])
+def test_featuriser_on_the_audio_the_reference_ships(name):
+    """The reference's own renderings (tests/golden/wav/, cut by tests/golden/make_wav_fixtures.py) through both of its
+    call paths -- get_melspectrogram_db_tensor_from_file (channel mean, whole file, file's sample rate: util.py:89-100)
+    and InputSong (channel 0, 5-second windows: GAN_DES/datasets.py:17-52) -- on the device against oracle/mel.py.
+    STILL PARITY UNPINNED (torchaudio is absent and the reference holds no spectrogram fixture): this pins the HIP path
+    to the restated algorithm on real programme material instead of synthetic tones."""
+    import os
+    from gan_des_midi_music_gen_amd import util
+    wav, sr = _read_wav(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wav", name))
+    for x in (wav.mean(axis=0), wav[0][: 5 * sr]):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        want = om.get_melspectrogram_db_tensor(x, sr=sr)
+        got = util.get_melspectrogram_db_tensor(torch.from_numpy(x).cuda(), sr=sr).cpu().numpy()
+        assert got.shape == want.shape == (128, 216)
+        loud = want > want.max() - 60.0
+        assert np.abs(got - want)[loud].max() < 0.02, np.abs(got - want)[loud].max()
+        assert np.abs(got - want).max() < 0.5

@@ -585,3 +585,31 @@ def test_non_finite_values_are_reported_like_anomaly_mode():
         with pytest.raises(ops.NonFiniteError):
             disc3(bad)
     assert int(ops.nonfinite_count([bad, real.bfloat16(), torch.tensor([float("-inf")], device=DEV)]).item()) == 2
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_one_launch_optimizer_step_equals_the_four_launch_chain(dtype):
+    """disc_opt.step() (GAN_DES/SIMNN.py:316) as ONE launch (gdm_simnn_adam_step: bias-correction terms, Adam on the
+    small parameters, transposing Adam on fc1.weight, conv2 re-pack) against adam_prep -> Adam -> Adam_pc -> re-pack:
+    parameters, moments, the packed conv2 images, fc1's operand copy, losses and the device step counter bit for bit."""
+    hw, b = (32, 40), 4
+    runs = []
+    for one in (True, False):
+        gen, disc = _build(11, True, input_hw=hw)
+        gen.to(DEV), disc.to(DEV)
+        tr = SimnnTrainer(gen, disc, compute_dtype=dtype, one_launch_optimizer=one)
+        losses = []
+        for it in range(4):
+            real, fake, noise = synthetic.simnn_inputs(b, hw, seed=40 + it, device=DEV)
+            dl, gl = tr.step(real, noise, fake)
+            losses.append((dl.item(), gl.item()))
+            if it == 1:
+                tr.lr = 1e-5                       # a hyper-parameter change between steps (device record rewritten)
+        torch.cuda.synchronize()
+        runs.append((losses, tr.d.flat.clone(), tr.d.exp_avg.clone(), tr.d.exp_avg_sq.clone(), tr._prepared[0].clone(),
+                     tr._prepared[1].clone(), int(tr.d._hyper.view(torch.int32)[0].item()), tr.d.step_count))
+    a, c = runs
+    assert a[0] == c[0], (a[0], c[0])
+    for k in range(1, 6):
+        assert torch.equal(a[k], c[k]), k
+    assert a[6] == c[6] == 4 and a[7] == c[7] == 4

@@ -30,16 +30,12 @@ copy(os.path.join(out, "step_breakdown.txt"), f"{tag}_simnn_b256_bf16_step_break
 copy(os.path.join(out, "bench_default.json"), f"{tag}_bench_default.json")
 copy(os.path.join(out, "bench_mmgan.json"), f"{tag}_bench_mmgan.json")
 copy(os.path.join(out, "pmc_ops_summary.txt"), f"{tag}_conv_kernels_b512_pmc_sq.txt")
-for name in ("bench_simnn_eager", "bench_simnn_elided", "bench_simnn_nopipeline", "bench_simnn_fp32", "bench_mmgan_eager",
+for name in ("bench_default_20", "bench_simnn_fp32_nopipeline", "bench_simnn_eager", "bench_simnn_elided", "bench_simnn_nopipeline", "bench_simnn_fp32", "bench_mmgan_eager",
              "bench_mmgan_b16", "bench_simnn_c1_b16_w64", "bench_simnn_c1_b16_w216", "bench_simnn_c5_b128_w216"):
     copy(os.path.join(out, name + ".json"), f"{tag}_{name}.json")
-copy(os.path.join(out, "pytest_gpu_r02.log"), f"{tag}_pytest_gpu.log")
-copy(os.path.join(out, "parity_r02.jsonl"), f"{tag}_parity_measurements.jsonl")
+copy(os.path.join(out, f"pytest_gpu_{tag}.log"), f"{tag}_pytest_gpu.log")
+copy(os.path.join(out, f"parity_{tag}.jsonl"), f"{tag}_parity_measurements.jsonl")
 copy(os.path.join(out, "mmgan_replay_timeline.txt"), f"{tag}_mmgan_replay_timeline.txt")
-copy(os.path.join(out, "r2_ko1.log"), f"{tag}_fused_bwd_knockout.txt")
-copy(os.path.join(out, "r2_overlap.log"), f"{tag}_conv_bwd_side_by_side.txt")
-copy(os.path.join(out, "r2_streams.log"), f"{tag}_stream_concurrency.txt")
-copy(os.path.join(out, "r2_stamps_occ.log"), f"{tag}_stamps_vs_occupancy.txt")
 
 # bench.py reads the dominant kernel's measured HBM bytes per launch from profiles/traffic.json
 src = os.path.join(out, "hbm_traffic.json")
@@ -47,7 +43,18 @@ if os.path.exists(src):
     d = json.load(open(src))
     fused = [v for k, v in d.items() if "conv2_bwd_data_kernel" in k and "true" in k]
     if fused:
+        # whole-iteration traffic: every kernel's bytes x its launches, over the iterations of the counter passes (Adam on
+        # fc1.weight runs once per iteration); algorithmic bytes per step from SURVEY.md section 8d (B = 256, 128x256:
+        # 395.2 KB of data per sample + 504 MB of parameter / optimizer traffic; code2 is half as wide since round 3)
+        adam = [v for k, v in d.items() if "adam_dev_pc" in k]
+        iters = adam[0]["launches"] if adam else 1
+        step_bytes = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in d.values()) / iters
         t = {"simnn_bf16": int(fused[0]["hbm_bytes_per_launch"]),
+             "simnn_bf16_step": {"measured_bytes_per_step": int(step_bytes),
+                                 "algorithmic_bytes_per_step": int(256 * 395.2e3 + 504e6),
+                                 "source": f"profiles/{tag}_simnn_b256_bf16_hbm_traffic.json (sum over all kernels of one "
+                                           "faithful iteration, rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes) over "
+                                           "SURVEY.md 8d's 605 MB"},
              "_source": f"profiles/{tag}_simnn_b256_bf16_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                         "passes, FETCH_SIZE x2 on gfx950), average over the 2B and B launches of one faithful iteration; "
                         "kernel: conv2_bwd_data_kernel<FUSE>"}
