@@ -82,6 +82,8 @@ def parse():
                     help="model 1: run the generator half of an iteration inside the same call (SimnnTrainer.step)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-overlap", action="store_true", help="single stream (no concurrent branches)")
+    ap.add_argument("--prime", type=int, default=40,
+                    help="untimed set-up iterations BEFORE the W warm-up steps (device start-up transient, see measure())")
     ap.add_argument("--pieces", action="store_true",
                     help="model 1 on one rank: replay the five-graph form N > 1 ranks use (around the all-reduces)")
     return ap.parse_args()
@@ -328,6 +330,14 @@ def measure(args, rank, world, dev, barrier, dist):
     gc.collect()
     gc.disable()
     try:
+        # Device start-up transient (tools/experiments/replay_transient.py, profiles/r03_replay_transient.txt): coming from
+        # an idle device, the first replay takes 1.09 ms, replays 4-10 0.70-0.75 ms, and the iteration only settles at its
+        # steady 0.61 ms after ~30-40 replays (~25 ms of work: clocks and the relative phase of the two replay streams).
+        # A 5-step warm-up + 20 timed steps measures that transient (0.66 ms), not the training rate.  `--prime` untimed
+        # iterations (default 40, reported in the JSON line) run as part of set-up, then the W warm-up steps, then
+        # exactly K timed steps between the barriers.
+        for _ in range(max(0, args.prime)):
+            step()
         for _ in range(args.warmup):
             step()
         barrier()
@@ -431,7 +441,7 @@ def secondary_lines(args, rank, dev, barrier):
         a = copy.copy(args)
         for k, v in over.items():
             setattr(a, k, v)
-        a.steps, a.warmup = 50, 10
+        a.steps, a.warmup, a.prime = 50, 10, 20
         torch.cuda.empty_cache()
         r = measure(a, rank, 1, dev, barrier, None)
         out[name] = {"ms_per_step": round(1e3 * r["elapsed"] / a.steps, 4),
@@ -470,7 +480,7 @@ def main():
         total = world * args.batch * args.steps
         out = {
             "metric": "GAN training samples/sec (G+D step)", "value": round(total / elapsed, 2), "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "priming_steps": max(0, args.prime),
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
             "config": {

@@ -1154,6 +1154,10 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
     const int b = cur.b, c0 = cur.c0, rq = cur.rq, rq_first = cur.rq_first;
     // ---- consume the prefetched registers into the LDS images of this step
     STAMP(3);
+#ifdef GDM_STAMPS
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // (stamp builds: this set's 12 loads have landed; the other set's 12 fly)
+    STAMP(6);
+#endif
     bd_expand<T, FUSE, XVEC>(rg, ln, rq, dc_s, tab_s);
     uint64_t codes[FUSE ? 4 : 1];
     if constexpr (FUSE) {
@@ -1762,7 +1766,8 @@ inline BdPlan bw_plan(int B, int H1, int W1) {
   // measured at 2B = 512 (1024 strips): 768 workgroups (3 per CU) 73 us, 1024 (4 per CU) 84 us, 512 78 us; finer items
   // (more segments per strip) only add pseudo steps
   static const int cap = tuned_cap("GDM_BW_CAP", 768);
-  int nseg = (int)((1024 + strips - 1) / strips);
+  static const int nseg_exp = tuned_cap("GDM_BW_NSEG", 0);          // experiments only
+  int nseg = nseg_exp > 0 ? nseg_exp : (int)((1024 + strips - 1) / strips);
   const int max_seg = nrq / 2 > 1 ? nrq / 2 : 1;
   nseg = nseg < 1 ? 1 : (nseg > max_seg ? max_seg : nseg);
   p.seg_len = (nrq + nseg - 1) / nseg;

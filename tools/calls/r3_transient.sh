@@ -1,0 +1,2 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 300 python tools/experiments/replay_transient.py 80

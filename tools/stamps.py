@@ -33,7 +33,7 @@ def main():
     p2, code2 = ops.simnn_conv2_fwd(p1, pack, b2)
     dp2 = torch.randn_like(p2.float()).to(torch.bfloat16)
     names = {"fwd": ["store->barrier", "issue", "mfma", "epilogue", "end barrier", "prologue", "wait+ds_write", "-"],
-             "bwd": ["barrier after expand", "issue (loads 2 steps ahead)", "data-gradient mfma", "loop bookkeeping", "conv1-dW epilogue", "end barrier", "prologue", "wait for loads + expand + x planes"],
+             "bwd": ["barrier after expand", "issue (loads 2 steps ahead)", "data-gradient mfma", "loop bookkeeping", "conv1-dW epilogue", "end barrier", "prologue + WAIT FOR THIS STEP'S LOADS", "expand + x planes"],
              "bww": ["barrier", "issue", "mfma", "end barrier", "prologue", "wait for loads", "expand + p1 store", "-"]}[which]
     fn = {"fwd": lambda: ops.simnn_conv2_fwd(p1, pack, b2),
           "bwd": lambda: ops.simnn_conv2_bwd_fused(dp2, code2, pack, code1, x),
