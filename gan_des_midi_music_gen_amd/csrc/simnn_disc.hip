@@ -243,7 +243,10 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
   // DEPTH units in flight per wave; every trip issues the same loads and stores (units past the end re-read valid
   // memory and their stores are dropped), so the waits between them are exact counts.  The sched_barriers keep the
   // compiler from sinking the refill loads below the next unit's MFMAs (which would expose their latency again).
-  constexpr int DEPTH = 4;
+#ifndef GDM_C1_DEPTH
+#define GDM_C1_DEPTH 4
+#endif
+  constexpr int DEPTH = GDM_C1_DEPTH;
   Slot q[DEPTH];
   float xv[DEPTH][4];
   q[0].seg = 0; q[0].ph = wave % H1; q[0].b = wave / H1;
@@ -460,7 +463,11 @@ template <typename T> struct C2 {
   static constexpr int WF_ELEMS = 32 * KPF, WB_ELEMS = 16 * KPB;
   static constexpr int S16 = Px<T>::S16, S32 = Px<T>::S32;
   static constexpr int WP = COLS + 2;
-  static constexpr int IN_ELEMS = (ROWS + 2) * WP * S16;     // p1 halo band
+  // records per parity plane of a band row in conv2 forward's even/odd-split image: WP / 2 = 33, padded to 34 -- with 33
+  // the four pixels of an 8-lane ds_write_b128 group (columns c, c+1, c+2, c+3 -> planes 0, 1, 0, 1) put two of them on the
+  // same 32 store banks (33 * 32 B = 32 mod 128): every band store was 2-way conflicted; 34 * 32 B = 64 mod 128 separates them
+  static constexpr int HP = WP / 2 + 1;
+  static constexpr int IN_ELEMS = (ROWS + 2) * 2 * HP * S16;     // p1 halo band (split image: 2 planes per row)
 };
 constexpr int XROWS = 2 * ROWS + 1;                          // input-window rows behind ROWS rows of the p1 geometry
 
@@ -576,7 +583,7 @@ __device__ __forceinline__ void p1_band_store(const P1Stage<T, NR>& st, T* __res
     int rec = pix;
     if constexpr (SPLIT) {
       const int cl = pix % WP, rl = pix / WP;
-      rec = (rl * 2 + (cl & 1)) * (WP / 2) + (cl >> 1);
+      rec = (rl * 2 + (cl & 1)) * C2<T>::HP + (cl >> 1);
     }
     T* dst = in_s + rec * S16 + piece * EPP;
     if constexpr (sizeof(T) == 2) *(f32x4*)dst = st.v[k];
@@ -597,7 +604,7 @@ template <typename T>
 __device__ __forceinline__ void conv2_fwd_tile(const T* __restrict__ in_s, const T* __restrict__ w_s,
                                                const float (&bo)[2][4], int b, int rq, int c0, int H2, int W2,
                                                rsrc_t p2r, rsrc_t code2r STAMP_ARG) {
-  constexpr int S16 = C2<T>::S16, KP = C2<T>::KPF, HP = C2<T>::WP / 2;
+  constexpr int S16 = C2<T>::S16, KP = C2<T>::KPF, HP = C2<T>::HP;
   const int t = threadIdx.x, l = t & 63, wv = t >> 6, lr = l & 15, lg = l >> 4;
   const int rp = wv >> 1, half = wv & 1;            // wave -> (pooled row of the tile, 32-column half)
   f32x4 acc[2][2][2];                               // [channel tile][row of the pair][column parity]
@@ -797,7 +804,11 @@ __global__ __launch_bounds__(256) void conv2_fwd_kernel(const T* __restrict__ p1
 // pooled pixel has an odd column index expand through them and store their first record one column to the right, their
 // second one to the left -- two neighbouring pooled pixels (128 bytes apart in a 64-byte-record image, i.e. on the same
 // 32 store banks) then hit opposite halves of the bank window: every expansion ds_write_b128 was 2-way conflicted.
-constexpr int C2T_SWAP = 256, C2T_C = 512, C2T_B = 2304, C2T_BYTES = C2T_B + 512;
+// (A' is shifted by 13 entries against A inside the 256-byte bank window: an A read and an A' read of the same half-wave
+// then collide only for entry pairs (e, e + 13), not for equal entries -- "both channels dead" is by far the most common.)
+constexpr int C2T_SWAP = 256 + 104, C2T_C = 576, C2T_B = 2304, C2T_BYTES = (C2T_B + C2T_SWAP + 256 + 15) / 16 * 16;
+static_assert(C2T_BYTES % 16 == 0, "what follows the tables in LDS is read with 16-byte accesses (a misaligned "
+                                   "ds_read_b128 is replayed at 64 cycles per wave instruction: the kernel ran 45 % slower)");
 __device__ __forceinline__ void code2_tables_init(uint32_t* tab) {
   const int e = threadIdx.x;
   if (e < 25) {
