@@ -50,6 +50,9 @@ SIGNATURES = {
     "gdm_bn_act_fwd": (_I, [_P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _I, _P, _I, _P, _P, _I, _P, _Z, _P]),
     "gdm_bn_act_bwd": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _Z, _P]),
     "gdm_bn_stats": (_I, [_P, _I, _I, _P, _P, _P, _F, _F, _P, _P, _P, _Z, _P]),
+    "gdm_bn_partial_chunks": (_I, [_I]),
+    "gdm_bn_partials": (_I, [_P, _I, _I, _P, _P]),
+    "gdm_bn_apply": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P]),
     "gdm_bn_finalize": (_I, [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "gdm_simnn_gen_pack_bytes": (_Z, []),
     "gdm_simnn_gen_pack": (_I, [_P, _I, _P, _P, _P, _P]),

@@ -471,6 +471,39 @@ extern "C" int gdm_bn_act_fwd(const float* y, int rows, int channels, const floa
   return GDM_OK;
 }
 
+// The two halves of training-mode batch norm as entry points of their own, for statistics that span more than one
+// call: gdm_bn_partials leaves the per-row-chunk Welford triples (n, mean, M2) of y in `partials`
+// (gdm_bn_partial_chunks(rows) x channels x 3 floats); partials of several batches (ranks) concatenated along the chunk
+// axis go through gdm_bn_finalize (fixed-order merge -> mean, invstd, running statistics); gdm_bn_apply normalises.
+extern "C" int gdm_bn_partial_chunks(int rows) { return row_chunks(rows); }
+
+extern "C" int gdm_bn_partials(const float* y, int rows, int channels, float* partials, void* stream) {
+  GDM_REQUIRE(y && partials && rows > 0 && channels > 0, "gdm_bn_partials: bad arguments");
+  const int C = channels, chunks = row_chunks(rows), chunk_rows = (rows + chunks - 1) / chunks;
+  int cw = 64;
+  while (cw / 2 >= C && cw > 1) cw /= 2;
+  hipLaunchKernelGGL(bn_partial_stats, dim3((C + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, y, rows, C,
+                     chunk_rows, cw, partials);
+  GDM_LAUNCH_OK("gdm_bn_partials");
+  return GDM_OK;
+}
+
+extern "C" int gdm_bn_apply(const float* y, int rows, int channels, const float* gamma, const float* beta,
+                            const float* mean, const float* invstd, int act, void* out, int out_dtype, void* stream) {
+  GDM_REQUIRE(y && gamma && beta && mean && invstd && out && rows > 0 && channels > 0 && gdm_dtype_ok(out_dtype),
+              "gdm_bn_apply: bad arguments");
+  const int64_t total = (int64_t)rows * channels;
+  hipStream_t s = (hipStream_t)stream;
+  if (total < ((int64_t)1 << 31))
+    hipLaunchKernelGGL(bn_apply<int>, dim3(grid_for(total)), dim3(256), 0, s, y, total, channels, gamma, beta, mean, invstd,
+                       act, out, out_dtype);
+  else
+    hipLaunchKernelGGL(bn_apply<int64_t>, dim3(grid_for(total)), dim3(256), 0, s, y, total, channels, gamma, beta, mean,
+                       invstd, act, out, out_dtype);
+  GDM_LAUNCH_OK("gdm_bn_apply");
+  return GDM_OK;
+}
+
 extern "C" int gdm_bn_finalize(const float* ws, int chunks, int rows, int channels, float momentum, float eps,
                                float* running_mean, float* running_var, int64_t* num_batches_tracked, float* save_mean,
                                float* save_invstd, void* stream) {

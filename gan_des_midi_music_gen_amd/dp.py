@@ -69,3 +69,14 @@ def allreduce_async_(tensor, group=None):
     if world_size(group) <= 1:
         return None
     return dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def all_gather_cat(tensor, group=None):
+    """Concatenation along dim 0 of every rank's ``tensor`` (same shape on all ranks), in rank order; the tensor itself
+    on a single rank.  Used for the exact global-batch BatchNorm statistics (per-rank Welford partials)."""
+    w = world_size(group)
+    if w <= 1:
+        return tensor
+    parts = [torch.empty_like(tensor) for _ in range(w)]
+    dist.all_gather(parts, tensor.contiguous(), group=group)
+    return torch.cat(parts, dim=0)

@@ -433,6 +433,23 @@ def mlp_bn_sigmoid_backward(saved, dout, layers, dt, need_dx=True):
     return d, grads
 
 
+def mlp_bn_sigmoid_forward_global(x, layers, group=None):
+    """Train-mode generator MLP (network_tests.py:75-80, 110-115) whose BatchNorm1d statistics are taken over the GLOBAL
+    batch of a data-parallel job (SURVEY.md 8e "exact mode"): every rank computes y = x W^T + b on its shard (exact-fp32
+    MFMA), its per-row-chunk Welford triples, all ranks exchange those (a few KB per layer) and merge them in rank order
+    (gdm_bn_finalize: identical on every rank, running statistics updated with the global batch), then normalise +
+    sigmoid.  With equal shards the result equals one process on the concatenated batch up to summation order."""
+    from . import dp
+    world = dp.world_size(group)
+    h = _f32c(x)
+    for (w, b, gamma, beta, rm, rv, nbt) in layers:
+        y = ops.gemm(h, w.t(), bias_n=b, compute=F32)
+        part = dp.all_gather_cat(ops.bn_partials(y), group)
+        mean, invstd = ops.bn_finalize(part, part.shape[0], y.shape[0] * world, y.shape[1], rm, rv, nbt)
+        h = ops.bn_apply(y, gamma, beta, mean, invstd, act=ACT_SIGMOID)
+    return h
+
+
 @_anomaly_guard
 class MlpBnSigmoidFn(torch.autograd.Function):
     """args: x, then per layer (W, b, gamma, beta) x L, then buffers tuple ((rm, rv, nbt) x L), training, dtype."""

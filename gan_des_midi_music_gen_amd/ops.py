@@ -251,6 +251,27 @@ def bn_stats(y, running_mean, running_var, nbt, *, momentum=0.1, eps=1e-5):
     return mean, invstd
 
 
+def bn_partials(y):
+    """Per-row-chunk Welford triples (chunks, C, 3) of y (rows, C) fp32 -- the first half of training-mode batch norm."""
+    _need_gpu(y)
+    assert y.dim() == 2 and y.dtype == torch.float32 and y.is_contiguous()
+    rows, c = y.shape
+    chunks = _lib.load().gdm_bn_partial_chunks(rows)
+    partials = torch.empty((chunks, c, 3), dtype=torch.float32, device=y.device)
+    _call("gdm_bn_partials", _p(y), rows, c, _p(partials), _stream())
+    return partials
+
+
+def bn_apply(y, gamma, beta, mean, invstd, *, act, out_dtype=F32):
+    """act((y - mean) * invstd * gamma + beta) with given per-column statistics."""
+    _need_gpu(y, gamma, beta, mean, invstd)
+    assert y.dim() == 2 and y.dtype == torch.float32 and y.is_contiguous()
+    rows, c = y.shape
+    out = torch.empty((rows, c), dtype=_TORCH_DT[out_dtype], device=y.device)
+    _call("gdm_bn_apply", _p(y), rows, c, _p(gamma), _p(beta), _p(mean), _p(invstd), act, _p(out), out_dtype, _stream())
+    return out
+
+
 def bn_finalize(partials, chunks, rows, c, running_mean, running_var, nbt, *, momentum=0.1, eps=1e-5):
     """Merge (chunks, c, 3) Welford partials -> (mean, invstd); running statistics updated."""
     _need_gpu(partials, running_mean, running_var, nbt)

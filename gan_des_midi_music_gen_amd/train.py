@@ -718,9 +718,12 @@ class MmganTrainer(_TrainerBase):
     """
 
     def __init__(self, mmgan, lr=0.01, betas=(0.9, 0.999), eps=1e-8, compute_dtype=None, elide_dead_backward=False,
-                 process_group=None, fuse_optimizer=True):
+                 process_group=None, fuse_optimizer=True, exact_bn=False):
         self.mm = mmgan
         self.fuse_optimizer = fuse_optimizer      # one rank, fused bf16 path: Adam + re-pack inside the gradient's slab sum
+        # N > 1 ranks: generators' BatchNorm1d statistics over the GLOBAL batch (per-layer exchange of Welford partials)
+        # instead of per rank -- generated matrices and running statistics then equal a single process on the whole batch
+        self.exact_bn = exact_bn
         d = mmgan.discriminator
         self._init_common([d.conv1.weight, d.conv1.bias, d.conv2.weight, d.conv2.bias, d.fc.weight, d.fc.bias], lr,
                           betas, eps, compute_dtype, elide_dead_backward, process_group)
@@ -829,6 +832,18 @@ class MmganTrainer(_TrainerBase):
         Returns (g1_a, g2_a, g1_b, g2_b); falls back to two sequential forwards where the fused block does not apply."""
         mm, dt = self.mm, self.dt
         b = len(noise1)
+        if self.exact_bn and self.world > 1 and mm.generator1.training and mm.generator2.training:
+            if g1_in_a is None:
+                g1_in_a = torch.randn(b, mm.generator1.input_tensor_dim).to(noise1.device)
+            if g1_in_b is None:
+                g1_in_b = torch.randn(b, mm.generator1.input_tensor_dim).to(noise1.device)
+            a = mm.generator1.adj_size
+            outs = []
+            for g1_in in (g1_in_a, g1_in_b):     # the reference's call order: G1, G2 (294), then G1, G2 again (312)
+                o1 = Fn.mlp_bn_sigmoid_forward_global(torch.cat((noise1, g1_in), dim=1), self._layers(mm.generator1), self.pg)
+                o2 = Fn.mlp_bn_sigmoid_forward_global(torch.cat((noise2, beats), dim=1), self._layers(mm.generator2), self.pg)
+                outs += [o1.view(b, -1, a[0], a[1]), o2]
+            return tuple(outs)
         fused = self._gen_fused_ok(b)
         if not fused:
             g1a, g2a = self._generators_forward(noise1, noise2, beats, g1_in_a, streams)

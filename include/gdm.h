@@ -100,6 +100,14 @@ int gdm_bn_act_bwd(const void* dout, const void* out, int out_dtype, const float
 int gdm_bn_stats(const float* y, int rows, int channels, float* running_mean, float* running_var,
                  int64_t* num_batches_tracked, float momentum, float eps, float* save_mean, float* save_invstd,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* Batch statistics that span several calls (data-parallel ranks, SURVEY.md 8e "exact mode"): gdm_bn_partials writes the
+ * per-row-chunk Welford triples (n, mean, M2) of y (rows, channels) into partials (gdm_bn_partial_chunks(rows) x channels
+ * x 3 floats); the partials of all ranks, concatenated along the chunk axis (all-gather), go through gdm_bn_finalize with
+ * the GLOBAL row count; gdm_bn_apply = act((y - mean) * invstd * gamma + beta). */
+int gdm_bn_partial_chunks(int rows);
+int gdm_bn_partials(const float* y, int rows, int channels, float* partials, void* stream);
+int gdm_bn_apply(const float* y, int rows, int channels, const float* gamma, const float* beta, const float* mean,
+                 const float* invstd, int act, void* out, int out_dtype, void* stream);
 int gdm_bn_finalize(const float* ws, int chunks, int rows, int channels, float momentum, float eps, float* running_mean,
                     float* running_var, int64_t* num_batches_tracked, float* save_mean, float* save_invstd, void* stream);
 

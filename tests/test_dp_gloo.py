@@ -60,6 +60,12 @@ def _worker(rank, world, port, out_dir):
     # ... and the single-collective form (model 2) covers exactly the same range
     assert fb.bucket_reduced().data_ptr() == fb.bucket_head().data_ptr()
     assert fb.bucket_reduced().numel() == fb.bucket_head().numel() + fb.bucket_big().numel()
+    # the exchange of per-rank BatchNorm Welford partials (exact global-batch statistics): rank order, every rank alike
+    part = torch.full((3, 5, 3), float(rank)) + torch.arange(3).view(3, 1, 1)
+    allp = dp.all_gather_cat(part)
+    assert allp.shape == (3 * world, 5, 3)
+    for r_ in range(world):
+        assert torch.equal(allp[3 * r_:3 * r_ + 3], torch.full((3, 5, 3), float(r_)) + torch.arange(3).view(3, 1, 1))
     if rank == 0:
         grads = torch.cat([g.reshape(-1) for g in fb.grad_views]) * scale      # caller's parameter order
         torch.save({"grads": grads, "loss": fb.extra[4].item() * scale, "numel": fb.numel},

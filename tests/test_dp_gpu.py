@@ -78,6 +78,24 @@ for kind in ("eager", "graph"):
     out["mmgan_bf16_" + kind] = {"d_loss": mt.disc_loss_value(), "g_loss": mt.gen_loss_global(),
                                  "fc": mm.discriminator.fc.weight.detach().cpu(),
                                  "c1": mm.discriminator.conv1.weight.detach().cpu()}
+# exact global-batch BatchNorm statistics for the generators (SURVEY.md 8e "exact mode"): with 2 ranks the generated
+# matrices / parameters and the running statistics must equal ONE process on the whole batch (world = 1: same code path off)
+torch.manual_seed(0)
+mm = NT.MultiModalGAN(z_dim=50, adj_size=(64, 64), roll_size=(2, 128, 50), input_dim=50, output_dim=20, device=dev)
+me = MmganTrainer(mm, compute_dtype="fp32", exact_bn=True)
+for it in range(2):
+    d = synthetic.mmgan_inputs(GB, 50, seed=980 + it, device=dev)
+    sl = slice(lo, hi)
+    me.step(d["piano_roll"][sl].contiguous(), d["durations"][sl].contiguous(), d["beats"][sl].contiguous(),
+            d["noise1"][sl].contiguous(), d["noise2"][sl].contiguous(), d["fake_a"][sl].contiguous(),
+            d["fake_b"][sl].contiguous(), g1_in_a=d["g1_in_a"][sl].contiguous(), g1_in_b=d["g1_in_b"][sl].contiguous())
+torch.cuda.synchronize()
+g1_all = dp.all_gather_cat(me.last_g1.contiguous()) if world > 1 else me.last_g1
+g2_all = dp.all_gather_cat(me.last_g2.contiguous()) if world > 1 else me.last_g2
+out["mmgan_exact_bn"] = {"g1": g1_all.detach().cpu(), "g2": g2_all.detach().cpu(),
+                         "rv": mm.generator1.gen[3][1].running_var.detach().cpu(),
+                         "rm": mm.generator2.gen[0][1].running_mean.detach().cpu(),
+                         "nbt": int(mm.generator1.gen[0][1].num_batches_tracked.item())}
 # model 1 on the benchmarked path (bf16, pipelined schedule): eager calls vs the five-graph replay around the two eager
 # collectives (train.SimnnTrainer._capture_pieces) -- what N > 1 ranks run in bench.py
 real, fake, noise = (t[lo:hi].contiguous() for t in synthetic.simnn_inputs(GB, hw, seed=970, device=dev))
@@ -147,6 +165,11 @@ def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path):
         assert e["d_loss"] == g["d_loss"] and e["g_loss"] == g["g_loss"] and e["g_loss_mid"] == g["g_loss_mid"]
         for k in ("fc1", "c1", "gen", "bn"):
             assert torch.equal(e[k], g[k]), ("model 1 pieces replay vs eager", k)
+    # exact global-batch BatchNorm: two ranks' generators see the statistics of the whole batch
+    a, b = one["mmgan_exact_bn"], two["mmgan_exact_bn"]
+    assert a["nbt"] == b["nbt"] == 4
+    for k in ("g1", "g2", "rv", "rm"):
+        assert (a[k] - b[k]).abs().max().item() < 2e-5 * max(1.0, a[k].abs().max().item()), ("exact_bn", k)
     for model in ("simnn", "simnn_pipelined", "mmgan"):
         a, b = one[model], two[model]
         assert abs(a["d_loss"] - b["d_loss"]) < 1e-5 * max(1.0, abs(a["d_loss"])), (model, a["d_loss"], b["d_loss"])
