@@ -2,7 +2,7 @@
 start offset, duration, queue and name of every kernel between two consecutive Adam launches."""
 import csv, sys, glob
 d = sys.argv[1]
-f = glob.glob(d + '/*/*_kernel_trace.csv')[0]
+f = max(glob.glob(d + '/*/*_kernel_trace.csv'), key=__import__('os').path.getmtime)     # newest run in the directory
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'adam_dev_kernel' in r['Kernel_Name']]

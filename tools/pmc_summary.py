@@ -1,6 +1,6 @@
 import csv,sys,glob,collections
 def load(d):
-    f=glob.glob(d+'/*/*_counter_collection.csv')[0]
+    f = max(glob.glob(d+'/*/*_counter_collection.csv'), key=__import__('os').path.getmtime)     # newest run in the directory
     rows=list(csv.DictReader(open(f)))
     agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(set)
     for r in rows:

@@ -2,7 +2,8 @@
 """Per-kernel launch durations of a rocprofv3 kernel trace, split into the long (2B batch) and short (B batch) launches:
 tools/trace_split.py gpurun_out/<dir>"""
 import csv, glob, collections, sys
-f = sorted(glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv'))[-1]
+import os
+f = max(glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv"), key=os.path.getmtime)
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     d[r['Kernel_Name']].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
