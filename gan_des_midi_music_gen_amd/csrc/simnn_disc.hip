@@ -517,17 +517,47 @@ __global__ __launch_bounds__(256) void simnn_adam_kernel(float* __restrict__ p, 
     const int bx = blk % tiles_x, by = (blk / tiles_x) % tiles_y, bz = blk / (tiles_x * tiles_y);
     adam_pc_tile<T>(tile, p, g_pc, m, v, C, P, shadow_pc, hyper, vec_ok, step_size, bc2_sqrt, bx, by, bz);
   } else {
+    // ONE workgroup for ~5 k elements + ~10 k packed values: every round trip counts, so each thread keeps U elements
+    // in flight (as a plain one-element loop this workgroup took 60 us, longer than the 16 k tile workgroups beside it)
     const float w1 = 1.0f - hyper[2], beta2 = hyper[3], omb2 = 1.0f - hyper[3], eps = hyper[4], gscale = hyper[5];
-    for (int i = threadIdx.x; i < n_small; i += 256)
-      adam_element(ps[i], ms[i], vs[i], gs[i], gscale, w1, beta2, omb2, eps, step_size, bc2_sqrt);
-    __syncthreads();                                       // conv2.weight (inside the small range) is up to date
-    for (int i = threadIdx.x; i < C2<T>::WF_ELEMS; i += 256) {
-      const int o = i / C2<T>::KPF, k = i % C2<T>::KPF;
-      wf[i] = from_f32<T>(k < 144 ? w2[(o * 16 + (k & 15)) * 9 + (k >> 4)] : 0.f);
+    constexpr int U = 8;
+    for (int i0 = threadIdx.x; i0 < n_small; i0 += 256 * U) {
+      float pj[U], mj[U], vj[U], gj[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + 256 * u, ic = i < n_small ? i : i0;
+        pj[u] = ps[ic]; mj[u] = ms[ic]; vj[u] = vs[ic]; gj[u] = gs[ic];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) adam_element(pj[u], mj[u], vj[u], gj[u], gscale, w1, beta2, omb2, eps, step_size, bc2_sqrt);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < n_small) { ps[i] = pj[u]; ms[i] = mj[u]; vs[i] = vj[u]; }
+      }
     }
-    for (int i = threadIdx.x; i < C2<T>::WB_ELEMS; i += 256) {
-      const int ci = i / C2<T>::KPB, k = i % C2<T>::KPB;
-      wb[i] = from_f32<T>(k < 288 ? w2[((k & 31) * 16 + ci) * 9 + (8 - (k >> 5))] : 0.f);
+    __syncthreads();                                       // conv2.weight (inside the small range) is up to date
+    for (int i0 = threadIdx.x; i0 < C2<T>::WF_ELEMS; i0 += 256 * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = min(i0 + 256 * u, C2<T>::WF_ELEMS - 1), o = i / C2<T>::KPF, k = i % C2<T>::KPF;
+        v[u] = k < 144 ? w2[(o * 16 + (k & 15)) * 9 + (k >> 4)] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (i0 + 256 * u < C2<T>::WF_ELEMS) wf[i0 + 256 * u] = from_f32<T>(v[u]);
+    }
+    for (int i0 = threadIdx.x; i0 < C2<T>::WB_ELEMS; i0 += 256 * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = min(i0 + 256 * u, C2<T>::WB_ELEMS - 1), ci = i / C2<T>::KPB, k = i % C2<T>::KPB;
+        v[u] = k < 288 ? w2[((k & 31) * 16 + ci) * 9 + (8 - (k >> 5))] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (i0 + 256 * u < C2<T>::WB_ELEMS) wb[i0 + 256 * u] = from_f32<T>(v[u]);
     }
   }
   __syncthreads();

@@ -46,7 +46,8 @@ if os.path.exists(src):
         # whole-iteration traffic: every kernel's bytes x its launches, over the iterations of the counter passes (Adam on
         # fc1.weight runs once per iteration); algorithmic bytes per step from SURVEY.md section 8d (B = 256, 128x256:
         # 395.2 KB of data per sample + 504 MB of parameter / optimizer traffic; code2 is half as wide since round 3)
-        adam = [v for k, v in d.items() if "adam_dev_pc" in k]
+        adam = [v for k, v in d.items() if "simnn_adam_kernel" in k or "adam_dev_pc" in k]
+        assert adam, "no optimizer kernel in the traffic profile: cannot count iterations"
         iters = adam[0]["launches"] if adam else 1
         step_bytes = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in d.values()) / iters
         t = {"simnn_bf16": int(fused[0]["hbm_bytes_per_launch"]),

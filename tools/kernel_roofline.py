@@ -11,7 +11,8 @@ traffic = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_simnn_b256_bf16_
 
 def short(n):
     n = n.replace("(anonymous namespace)::", "").replace("_ZN12_GLOBAL__N_1", "")
-    for key in ("conv2_bwd_data_kernel", "conv1_fwd_kernel", "conv2_bwd_weight_kernel", "conv2_fwd_kernel", "adam_dev_pc_kernel",
+    for key in ("conv2_bwd_data_kernel", "conv1_fwd_kernel", "conv2_bwd_weight_kernel", "conv2_fwd_kernel", "simnn_adam_kernel",
+                "adam_dev_pc_kernel",
                 "gemm_splitk_reduce", "gen_l1_kernel", "convt_k5_bn_sigmoid_kernel", "bn_finalize", "simnn_head_kernel",
                 "simnn_head_final", "adam_prep_kernel", "conv2_pack_kernel"):
         if key in n:
@@ -28,7 +29,7 @@ def short(n):
     return n[:40]
 
 
-adam = [r for r in stats if "adam_dev_pc" in r["Name"]]
+adam = [r for r in stats if "simnn_adam_kernel" in r["Name"] or "adam_dev_pc" in r["Name"]]
 iters = int(adam[0]["Calls"]) if adam else 1
 rows = []
 for r in stats:
