@@ -11,24 +11,32 @@ __device__ __forceinline__ void adam_derived(const float* hyper, int step, float
   bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)step));
 }
 
-// One (128 p x 32 c) tile of row n of an (N, C, P) parameter (gdm_adam_step_dev_pc, gdm_simnn_adam_step): see the
-// kernels that call it.  step_size / bc2_sqrt: the derived bias-correction terms of THIS step.
-template <typename TS>
-__device__ __forceinline__ void adam_pc_tile(float (&tile)[32][132], float* __restrict__ p, const float* __restrict__ g_pc,
-                                             float* __restrict__ m, float* __restrict__ v, int C, int P,
-                                             TS* __restrict__ shadow_pc, const float* __restrict__ hyper, int vec_ok,
-                                             float step_size, float bc2_sqrt, int bx, int by, int bz) {
-  const float w1 = 1.0f - hyper[2], beta2 = hyper[3], omb2 = 1.0f - hyper[3], eps = hyper[4], gscale = hyper[5];
+// One (128 p x 32 c) tile of row n of an (N, C, P) parameter (gdm_adam_step_dev_pc, gdm_simnn_adam_step), in two parts
+// with a workgroup barrier between them (the caller's): the gather of the gradient tile needs nothing but addresses,
+// so a caller that still waits for the step's bias-correction terms issues it first.
+__device__ __forceinline__ void adam_pc_gather(float (&tile)[32][132], const float* __restrict__ g_pc, int C, int P,
+                                               int bx, int by, int bz) {
   const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
-  const int p0 = bx * 128, c0 = by * 32, n = bz;
-  const int64_t base = (int64_t)n * C * P;
-  const bool full = vec_ok && p0 + 128 <= P && c0 + 32 <= C;      // 16-byte accesses to p, m, v
+  const int p0 = bx * 128, c0 = by * 32;
+  const int64_t base = (int64_t)bz * C * P;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {                                     // gradient tile, read along c
     const int pl = ty + 8 * i, pp = p0 + pl, c = c0 + tx;
     tile[tx][pl] = (pp < P && c < C) ? g_pc[base + (int64_t)pp * C + c] : 0.f;
   }
-  __syncthreads();
+}
+
+// step_size / bc2_sqrt: the derived bias-correction terms of THIS step.
+template <typename TS>
+__device__ __forceinline__ void adam_pc_update(float (&tile)[32][132], float* __restrict__ p, float* __restrict__ m,
+                                               float* __restrict__ v, int C, int P, TS* __restrict__ shadow_pc,
+                                               const float* __restrict__ hyper, int vec_ok, float step_size,
+                                               float bc2_sqrt, int bx, int by, int bz) {
+  const float w1 = 1.0f - hyper[2], beta2 = hyper[3], omb2 = 1.0f - hyper[3], eps = hyper[4], gscale = hyper[5];
+  const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+  const int p0 = bx * 128, c0 = by * 32, n = bz;
+  const int64_t base = (int64_t)n * C * P;
+  const bool full = vec_ok && p0 + 128 <= P && c0 + 32 <= C;      // 16-byte accesses to p, m, v
 #pragma unroll
   for (int i = 0; i < 4; ++i) {                                      // p, m, v along p: four elements per thread
     const int cl = ty + 8 * i, c = c0 + cl, pp = p0 + 4 * tx;
@@ -76,3 +84,13 @@ __device__ __forceinline__ void adam_pc_tile(float (&tile)[32][132], float* __re
   }
 }
 
+
+template <typename TS>
+__device__ __forceinline__ void adam_pc_tile(float (&tile)[32][132], float* __restrict__ p, const float* __restrict__ g_pc,
+                                             float* __restrict__ m, float* __restrict__ v, int C, int P,
+                                             TS* __restrict__ shadow_pc, const float* __restrict__ hyper, int vec_ok,
+                                             float step_size, float bc2_sqrt, int bx, int by, int bz) {
+  adam_pc_gather(tile, g_pc, C, P, bx, by, bz);
+  __syncthreads();
+  adam_pc_update<TS>(tile, p, m, v, C, P, shadow_pc, hyper, vec_ok, step_size, bc2_sqrt, bx, by, bz);
+}

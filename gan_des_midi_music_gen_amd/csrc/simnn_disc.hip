@@ -492,80 +492,159 @@ __global__ __launch_bounds__(256) void conv2_pack_kernel(const float* __restrict
 // ---- the discriminator's whole optimizer step in ONE launch -------------------------------------------------------------
 // disc_opt.step() (GAN_DES/SIMNN.py:316) was adam_prep -> Adam(small parameters) -> Adam(fc1.weight, transposing) ->
 // conv2 re-pack: four launches at the end of the iteration's critical chain (~15 us of launch tails for 5 us of work).
-// Here the grid is fc1.weight's (p, c, n) tiles plus ONE more workgroup that updates the 4.9 k small parameters and then
-// rebuilds conv2's packed MFMA images from the weights it has just written; every workgroup derives the step's
-// bias-correction terms itself from the device record, and the last one to finish advances the record's step counter
-// (all of them have read it by then).  Same arithmetic (adam_element, adam_derived): bit-identical to the four launches.
+// Here the grid is fc1.weight's (p, c, n) tiles, and workgroup 0 first updates the 4.9 k small parameters and rebuilds
+// conv2's packed MFMA images from the weights it has just written.  Same arithmetic (adam_element,
+// adam_derived): bit-identical to the four launches.
+//
+// The device record `rec` (GDM_SIMNN_ADAM_RECORD_INTS ints, zero before the first launch) carries what a launch needs
+// besides `hyper`:
+//   * completion counters in two levels -- rec[0] counts finished GROUPS, rec[REC_GROUP0 + 16 g] the finished workgroups
+//     of group g = block % 64, each on its own cache line: the workgroup that finishes last advances hyper's step
+//     counter (all have read it by then).  (Two levels keep 2 k returning atomics off ONE address, where L2 serialises
+//     them as the kernel ends; at this count the single counter measured the same, 61.0 vs 61.6 us.)
+//   * the bias-correction terms of a step, cached: slot (step & 1) = {step, step_size, sqrt(bias_correction2)}.  The
+//     workgroup 0 derives the NEXT step's terms (two double-precision pow) into the other slot, which nobody reads
+//     during this launch; a workgroup whose slot does not carry its step (first launch, record rewritten by the host:
+//     the host zeroes `rec` then) derives them itself.
+constexpr int REC_SLOT0 = 16, REC_GROUP0 = 32, REC_GROUPS = 64;
+constexpr int REC_INTS = REC_GROUP0 + 16 * REC_GROUPS;
 template <typename T>
-__global__ __launch_bounds__(256) void simnn_adam_kernel(float* __restrict__ p, const float* __restrict__ g_pc,
+__global__ __launch_bounds__(256, 8) void simnn_adam_kernel(float* __restrict__ p, const float* __restrict__ g_pc,
                                                          float* __restrict__ m, float* __restrict__ v, int C, int P,
                                                          T* __restrict__ shadow_pc, int vec_ok, int tiles_x, int tiles_y,
-                                                         int n_big_blocks, float* __restrict__ ps,
+                                                         int small_vec_ok, float* __restrict__ ps,
                                                          const float* __restrict__ gs, float* __restrict__ ms,
                                                          float* __restrict__ vs, int n_small,
                                                          const float* __restrict__ w2, T* __restrict__ wf,
-                                                         T* __restrict__ wb, float* __restrict__ hyper,
-                                                         int* __restrict__ done) {
-  __shared__ __attribute__((aligned(16))) float tile[32][132];
+                                                         T* __restrict__ wb, float* __restrict__ hyper, int* rec) {
+  __shared__ __attribute__((aligned(16))) float lds[4608];          // the tile; workgroup 0: conv2.weight before that
+  static_assert(sizeof(lds) >= sizeof(float[32][132]), "tile");
+  float (&tile)[32][132] = *reinterpret_cast<float (*)[32][132]>(lds);
   __shared__ float hy[2];
+  STAMP_DECL;
+  // hyper's step counter and BOTH slots are read at once (one round trip, not a dependent chain of three -- with 2 k
+  // workgroups streaming, a round trip is ~2 us), and a tile workgroup looks at them only after it has issued its
+  // gradient gather.
   const int step = __float_as_int(hyper[0]) + 1;
-  if (threadIdx.x == 0) adam_derived(hyper, step, hy[0], hy[1]);
-  __syncthreads();
-  const float step_size = hy[0], bc2_sqrt = hy[1];
+  const int tag0 = rec[REC_SLOT0], tag1 = rec[REC_SLOT0 + 4];
+  const float ss0 = __int_as_float(rec[REC_SLOT0 + 1]), bq0 = __int_as_float(rec[REC_SLOT0 + 2]);
+  const float ss1 = __int_as_float(rec[REC_SLOT0 + 5]), bq1 = __int_as_float(rec[REC_SLOT0 + 6]);
+  float step_size, bc2_sqrt;
+  auto resolve = [&]() {
+    const bool odd = step & 1;
+    step_size = odd ? ss1 : ss0;
+    bc2_sqrt = odd ? bq1 : bq0;
+    if ((odd ? tag1 : tag0) != step) {                     // uniform; first launch, or the host has rewritten the record
+      if (threadIdx.x == 0) adam_derived(hyper, step, hy[0], hy[1]);
+      __syncthreads();
+      step_size = hy[0]; bc2_sqrt = hy[1];
+    }
+  };
   const int blk = blockIdx.x;
-  if (blk < n_big_blocks) {
-    const int bx = blk % tiles_x, by = (blk / tiles_x) % tiles_y, bz = blk / (tiles_x * tiles_y);
-    adam_pc_tile<T>(tile, p, g_pc, m, v, C, P, shadow_pc, hyper, vec_ok, step_size, bc2_sqrt, bx, by, bz);
-  } else {
-    // ONE workgroup for ~5 k elements + ~10 k packed values: every round trip counts, so each thread keeps U elements
-    // in flight (as a plain one-element loop this workgroup took 60 us, longer than the 16 k tile workgroups beside it)
+  STAMP(0);
+  // Workgroup 0 (dispatched first) does the small work BEFORE its tile.  The 2 k tile workgroups are exactly the chip's
+  // 8 x 256 slots and run side by side for the whole kernel; a workgroup of its own for the small work either waits for
+  // a slot (as the last block: 61 us instead of 47) or takes one, and the tile workgroup it displaces then runs alone
+  // behind all the others (55 us).
+  if (blk == 0) {
+    resolve();
+    // ~5 k elements + ~10 k packed values in one workgroup, while 2 k others saturate the memory system: a dependent
+    // round trip costs ~5 us here, so what counts is their NUMBER.  The small range is read in rounds of 2 x 16 bytes
+    // per thread and array (all eight loads of a round in flight; more would push the kernel past 64 VGPRs: 7 workgroups
+    // per CU instead of 8, and the 2 k tile workgroups no longer run in one round), the updated conv2.weight stays in LDS
+    // and the packed images are built from there.
     const float w1 = 1.0f - hyper[2], beta2 = hyper[3], omb2 = 1.0f - hyper[3], eps = hyper[4], gscale = hyper[5];
-    constexpr int U = 8;
-    for (int i0 = threadIdx.x; i0 < n_small; i0 += 256 * U) {
-      float pj[U], mj[U], vj[U], gj[U];
+    const int w2_off = (int)(w2 - ps);
+    auto keep_w2 = [&](int i, float val) {
+      const unsigned j = (unsigned)(i - w2_off);
+      if (j < 4608u) lds[j] = val;
+    };
+    const int n4 = small_vec_ok ? n_small / 4 : 0;
+    constexpr int R = 2;
+    for (int v0 = threadIdx.x; v0 < n4; v0 += 256 * R) {
+      f32x4 pj[R], mj[R], vj[R], gj[R];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = i0 + 256 * u, ic = i < n_small ? i : i0;
-        pj[u] = ps[ic]; mj[u] = ms[ic]; vj[u] = vs[ic]; gj[u] = gs[ic];
+      for (int r = 0; r < R; ++r) {
+        const int iv = min(v0 + 256 * r, n4 - 1);
+        pj[r] = ((const f32x4*)ps)[iv]; mj[r] = ((const f32x4*)ms)[iv]; vj[r] = ((const f32x4*)vs)[iv];
+        gj[r] = ((const f32x4*)gs)[iv];
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) adam_element(pj[u], mj[u], vj[u], gj[u], gscale, w1, beta2, omb2, eps, step_size, bc2_sqrt);
+      for (int r = 0; r < R; ++r) {
+        const int iv = v0 + 256 * r;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = i0 + 256 * u;
-        if (i < n_small) { ps[i] = pj[u]; ms[i] = mj[u]; vs[i] = vj[u]; }
+        for (int e = 0; e < 4; ++e) {
+          float a = pj[r][e], bm = mj[r][e], bv = vj[r][e];
+          adam_element(a, bm, bv, gj[r][e], gscale, w1, beta2, omb2, eps, step_size, bc2_sqrt);
+          pj[r][e] = a; mj[r][e] = bm; vj[r][e] = bv;
+          if (iv < n4) keep_w2(4 * iv + e, a);
+        }
+        if (iv < n4) { ((f32x4*)ps)[iv] = pj[r]; ((f32x4*)ms)[iv] = mj[r]; ((f32x4*)vs)[iv] = vj[r]; }
       }
     }
-    __syncthreads();                                       // conv2.weight (inside the small range) is up to date
+    for (int i = 4 * n4 + threadIdx.x; i < n_small; i += 256) {      // the last n_small % 4 elements (all, if unaligned)
+      float a = ps[i], bm = ms[i], bv = vs[i];
+      adam_element(a, bm, bv, gs[i], gscale, w1, beta2, omb2, eps, step_size, bc2_sqrt);
+      ps[i] = a; ms[i] = bm; vs[i] = bv;
+      keep_w2(i, a);
+    }
+    __syncthreads();                                       // lds[0 .. 4607] = the updated conv2.weight
+    STAMP(1);
+    constexpr int U = 4;                                   // independent LDS reads per trip (one per trip: 15 us)
     for (int i0 = threadIdx.x; i0 < C2<T>::WF_ELEMS; i0 += 256 * U) {
-      float v[U];
+      float val[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int i = min(i0 + 256 * u, C2<T>::WF_ELEMS - 1), o = i / C2<T>::KPF, k = i % C2<T>::KPF;
-        v[u] = k < 144 ? w2[(o * 16 + (k & 15)) * 9 + (k >> 4)] : 0.f;
+        val[u] = k < 144 ? lds[(o * 16 + (k & 15)) * 9 + (k >> 4)] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (i0 + 256 * u < C2<T>::WF_ELEMS) wf[i0 + 256 * u] = from_f32<T>(v[u]);
+        if (i0 + 256 * u < C2<T>::WF_ELEMS) wf[i0 + 256 * u] = from_f32<T>(val[u]);
     }
     for (int i0 = threadIdx.x; i0 < C2<T>::WB_ELEMS; i0 += 256 * U) {
-      float v[U];
+      float val[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int i = min(i0 + 256 * u, C2<T>::WB_ELEMS - 1), ci = i / C2<T>::KPB, k = i % C2<T>::KPB;
-        v[u] = k < 288 ? w2[((k & 31) * 16 + ci) * 9 + (8 - (k >> 5))] : 0.f;
+        val[u] = k < 288 ? lds[((k & 31) * 16 + ci) * 9 + (8 - (k >> 5))] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (i0 + 256 * u < C2<T>::WB_ELEMS) wb[i0 + 256 * u] = from_f32<T>(v[u]);
+        if (i0 + 256 * u < C2<T>::WB_ELEMS) wb[i0 + 256 * u] = from_f32<T>(val[u]);
     }
+    STAMP(2);
+    if (threadIdx.x == 255) {                              // the next step's terms, into the slot this launch does not read
+      float ss, bq;
+      adam_derived(hyper, step + 1, ss, bq);
+      int* nxt = rec + REC_SLOT0 + 4 * ((step + 1) & 1);
+      nxt[1] = __float_as_int(ss); nxt[2] = __float_as_int(bq); nxt[0] = step + 1;
+    }
+    __syncthreads();                                       // the tile below reuses lds
+    STAMP(3);
+  }
+  {
+    const int bx = blk % tiles_x, by = (blk / tiles_x) % tiles_y, bz = blk / (tiles_x * tiles_y);
+    adam_pc_gather(tile, g_pc, C, P, bx, by, bz);
+    resolve();
+    __syncthreads();
+    adam_pc_update<T>(tile, p, m, v, C, P, shadow_pc, hyper, vec_ok, step_size, bc2_sqrt, bx, by, bz);
   }
   __syncthreads();
-  if (threadIdx.x == 0 && atomicAdd(done, 1) == (int)gridDim.x - 1) {
-    hyper[0] = __int_as_float(step);
-    hyper[6] = step_size;
-    hyper[7] = bc2_sqrt;
-    *done = 0;
+  STAMP(4);
+  STAMP_FLUSH;
+  if (threadIdx.x == 0) {
+    const int grp = (int)blockIdx.x % REC_GROUPS, n_grp = min((int)gridDim.x, REC_GROUPS);
+    const int in_grp = ((int)gridDim.x - grp + REC_GROUPS - 1) / REC_GROUPS;
+    if (atomicAdd(rec + REC_GROUP0 + 16 * grp, 1) == in_grp - 1) {
+      atomicExch(rec + REC_GROUP0 + 16 * grp, 0);          // nobody else touches this counter before the next launch
+      if (atomicAdd(rec, 1) == n_grp - 1) {
+        atomicExch(rec, 0);
+        hyper[0] = __int_as_float(step);
+        hyper[6] = step_size;
+        hyper[7] = bc2_sqrt;
+      }
+    }
   }
 }
 
@@ -1923,10 +2002,12 @@ extern "C" int gdm_simnn_adam_step(float* p_big, const float* g_big_pc, float* m
   const int64_t nbig = (int64_t)tx * ty * N;
   GDM_REQUIRE(nbig < ((int64_t)1 << 30), "gdm_simnn_adam_step: parameter too large");
   const int vec_ok = (P % 4 == 0) && ((((uintptr_t)p_big | (uintptr_t)m_big | (uintptr_t)v_big) & 15) == 0);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(simnn_adam_kernel<T>, dim3((unsigned)nbig + 1), dim3(256), 0, (hipStream_t)stream, p_big,
-                                       g_big_pc, m_big, v_big, C, P, (T*)shadow_pc, vec_ok, tx, ty, (int)nbig, p_small, g_small,
+  const int small_vec_ok = ((((uintptr_t)p_small | (uintptr_t)g_small | (uintptr_t)m_small | (uintptr_t)v_small) & 15) == 0);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(simnn_adam_kernel<T>, dim3((unsigned)nbig), dim3(256), 0, (hipStream_t)stream, p_big,
+                                       g_big_pc, m_big, v_big, C, P, (T*)shadow_pc, vec_ok, tx, ty, small_vec_ok, p_small, g_small,
                                        m_small, v_small, n_small, conv2_weight, (T*)pack, (T*)pack + C2<T>::WF_ELEMS, hyper,
                                        done));
+  static_assert(REC_INTS == GDM_SIMNN_ADAM_RECORD_INTS, "include/gdm.h states the record's size");
   GDM_LAUNCH_OK("gdm_simnn_adam_step");
   return GDM_OK;
 }

@@ -200,18 +200,22 @@ def adam_step_dev_pc(p, g_pc, m, v, n, c, pix, shadow_pc, hyper, advance_step=Fa
           _p(hyper), 1 if advance_step else 0, _stream())
 
 
+SIMNN_ADAM_RECORD_INTS = 1056     # GDM_SIMNN_ADAM_RECORD_INTS (include/gdm.h)
+
+
 def simnn_adam_step(p_big, g_big_pc, m_big, v_big, n, c, pix, shadow_pc, p_small, g_small, m_small, v_small, conv2_weight,
                     pack, hyper, done):
     """Model 1's whole discriminator optimizer step in one launch (gdm_simnn_adam_step): transposing Adam on the
     (n, c, pix) parameter, plain Adam on the contiguous small range (which holds ``conv2_weight``), re-pack of conv2's
-    MFMA images into ``pack``; the device step counter in ``hyper`` is advanced."""
+    MFMA images into ``pack``; the device step counter in ``hyper`` is advanced.  ``done``: the optimizer's int32 record
+    (SIMNN_ADAM_RECORD_INTS zeros at first; zero it again after rewriting ``hyper`` from the host)."""
     _need_gpu(p_big, g_big_pc, m_big, v_big, shadow_pc, p_small, g_small, m_small, v_small, conv2_weight, pack, hyper, done)
     for t in (p_big, g_big_pc, m_big, v_big):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n * c * pix
     for t in (p_small, g_small, m_small, v_small):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == p_small.numel()
     assert shadow_pc.is_contiguous() and shadow_pc.numel() == n * c * pix and conv2_weight.numel() == 4608
-    assert hyper.numel() == 8 and done.numel() == 1 and done.dtype == torch.int32
+    assert hyper.numel() == 8 and done.numel() == SIMNN_ADAM_RECORD_INTS and done.dtype == torch.int32
     dt = gdm_dtype(shadow_pc)
     assert pack.numel() == _lib.load().gdm_simnn_conv2_pack_bytes(dt)
     _call("gdm_simnn_adam_step", _p(p_big), _p(g_big_pc), _p(m_big), _p(v_big), n, c, pix, _p(shadow_pc), _p(p_small),

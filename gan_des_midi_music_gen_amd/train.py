@@ -83,6 +83,7 @@ class FlatBuffers:
             off += n
         self.step_count = 0
         self._hyper = None
+        self.derived_record = None   # device record holding values derived from _hyper (gdm_simnn_adam_step's)
         self._hyper_host = None
 
     # the two contiguous pieces of the data-parallel exchange
@@ -106,6 +107,8 @@ class FlatBuffers:
                 raise ops.GdmError("optimizer hyper-parameters changed inside a captured step: re-capture the graph")
             self._hyper[1:6].copy_(torch.tensor(want, dtype=torch.float32), non_blocking=False)
             self._hyper_host = want
+            if self.derived_record is not None:
+                self.derived_record.zero_()          # terms cached on the device for the old lr / betas
         return want
 
     def adam(self, lr, betas, eps, grad_scale=1.0, big_pc=None):
@@ -305,12 +308,14 @@ class SimnnTrainer(_TrainerBase):
             ops.simnn_conv2_pack(d.views[2], self.dt, out=self._prepared[0])
             return
         # one launch: adam_prep + Adam(small) + Adam(fc1.weight) + conv2 re-pack (gdm_simnn_adam_step)
+        if getattr(self, "_adam_done", None) is None:
+            # completion counters + cached bias-correction terms; sync_hyper zeroes it when it rewrites the record
+            self._adam_done = d.derived_record = torch.zeros(ops.SIMNN_ADAM_RECORD_INTS, dtype=torch.int32,
+                                                             device=d.flat.device)
         want = d.sync_hyper(self.lr, self.betas, self.eps, 1.0 / self.world)
         if d._hyper is None:
             d._hyper = ops.adam_hyper(d.flat.device, *want, step=d.step_count)
             d._hyper_host = want
-        if getattr(self, "_adam_done", None) is None:
-            self._adam_done = torch.zeros(1, dtype=torch.int32, device=d.flat.device)
         d.step_count += 1
         ns = d.n_small
         ops.simnn_adam_step(d.flat[ns:], d.grad[ns:], d.exp_avg[ns:], d.exp_avg_sq[ns:], n, 32, k // 32, self._prepared[1],

@@ -207,8 +207,11 @@ int gdm_simnn_conv1_bwd_data(const void* dp1, const uint64_t* code1, const float
  * gdm_adam_step_dev_pc (gradient and operand copy in (N,P,C) order) + Adam on the n_small remaining parameters (one
  * contiguous range p_small / g_small / m_small / v_small that contains conv2.weight) + the rebuild of conv2's packed
  * images (gdm_simnn_conv2_pack) from the updated weights.  hyper: the 8-float device record of gdm_adam_step_dev (its
- * step counter is advanced); done: one device int, zero before the first launch.  Bit-identical to the sequence
- * gdm_adam_step_dev(small) + gdm_adam_step_dev_pc(big) + gdm_simnn_conv2_pack. */
+ * step counter is advanced); done: a device record of GDM_SIMNN_ADAM_RECORD_INTS ints owned by this optimizer (two-level
+ * completion counters and the cached bias-correction terms of the next step), zero before the first launch and to be
+ * zeroed again whenever the host rewrites `hyper`.  Bit-identical to the sequence gdm_adam_step_dev(small) +
+ * gdm_adam_step_dev_pc(big) + gdm_simnn_conv2_pack. */
+#define GDM_SIMNN_ADAM_RECORD_INTS 1056
 int gdm_simnn_adam_step(float* p_big, const float* g_big_pc, float* m_big, float* v_big, int N, int C, int P,
                         void* shadow_pc, float* p_small, const float* g_small, float* m_small, float* v_small,
                         int n_small, const float* conv2_weight, void* pack, int dtype, float* hyper, int* done,
