@@ -1068,8 +1068,9 @@ __device__ __forceinline__ void bd_issue(BdStepRegs<T, FUSE, XVEC>& rg, const Bd
 
 // Registers of step rq -> ring rows 4rq+2 .. 4rq+5.  Lane = (pooled pixel, 8-channel group): four 16-byte records.
 // (OOB items loaded zeros: pair byte 0 = "both channels at position 0" of a zero gradient -> zeros everywhere.)
-template <typename T, bool FUSE, bool XVEC>
-__device__ __forceinline__ void bd_expand(const BdStepRegs<T, FUSE, XVEC>& rg, const BdLane<FUSE, XVEC>& ln, int rq,
+// slot0 = ring row of the step's first new conv row (even), RING = rows in the ring.
+template <typename T, bool FUSE, bool XVEC, int RING = BD_RING>
+__device__ __forceinline__ void bd_expand(const BdStepRegs<T, FUSE, XVEC>& rg, const BdLane<FUSE, XVEC>& ln, int slot0,
                                           T* __restrict__ dc_s, const unsigned char* __restrict__ tab) {
   constexpr int S32 = C2<T>::S32;
   const int og = threadIdx.x & 3;
@@ -1077,7 +1078,8 @@ __device__ __forceinline__ void bd_expand(const BdStepRegs<T, FUSE, XVEC>& rg, c
   for (int k = 0; k < BD_DCIT; ++k) {
     const int prow = ln.dc_prow[k], pcol = ln.dc_pcol[k];
     if (prow > 1) continue;
-    const int slot = (ROWS * rq + 2 + 2 * prow) & (BD_RING - 1);       // even: slot + 1 never wraps
+    int slot = slot0 + 2 * prow;                                         // even: slot + 1 never wraps
+    if (slot >= RING) slot -= RING;
     const uint32_t cd = rg.cd[k];
     if constexpr (sizeof(T) == 2) {
       const u32x4 gv = __builtin_bit_cast(u32x4, rg.g[k][0]);
@@ -1278,7 +1280,7 @@ __global__ __launch_bounds__(256) void conv2_bwd_data_kernel(const T* __restrict
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // (stamp builds: this set's 12 loads have landed; the other set's 12 fly)
     STAMP(6);
 #endif
-    bd_expand<T, FUSE, XVEC>(rg, ln, rq, dc_s, tab_s);
+    bd_expand<T, FUSE, XVEC>(rg, ln, (ROWS * rq + 2) & (BD_RING - 1), dc_s, tab_s);
     uint64_t codes[FUSE ? 4 : 1];
     if constexpr (FUSE) {
       if constexpr (MF) {

@@ -26,11 +26,15 @@ def main():
     p2, code2 = ops.simnn_conv2_fwd(p1, pack, b2)
     dp2 = torch.randn_like(p2.float()).to(torch.bfloat16)
     res = {}
-    res["conv1_fwd"] = timeit(lambda: ops.simnn_conv1_fwd(x, w1, b1, BF16))
-    res["conv2_fwd"] = timeit(lambda: ops.simnn_conv2_fwd(p1, pack, b2))
-    res["conv2_bwd_fused"] = timeit(lambda: ops.simnn_conv2_bwd_fused(dp2, code2, pack, code1, x))
-    res["conv2_bwd_data"] = timeit(lambda: ops.simnn_conv2_bwd_data(dp2, code2, pack, p1.shape[1], p1.shape[2]))
-    res["conv2_bwd_weight"] = timeit(lambda: ops.simnn_conv2_bwd_weight(dp2, code2, p1))
+    only = os.environ.get("ONLY")              # one op by name
+    fns = {"conv1_fwd": lambda: ops.simnn_conv1_fwd(x, w1, b1, BF16),
+           "conv2_fwd": lambda: ops.simnn_conv2_fwd(p1, pack, b2),
+           "conv2_bwd_fused": lambda: ops.simnn_conv2_bwd_fused(dp2, code2, pack, code1, x),
+           "conv2_bwd_data": lambda: ops.simnn_conv2_bwd_data(dp2, code2, pack, p1.shape[1], p1.shape[2]),
+           "conv2_bwd_weight": lambda: ops.simnn_conv2_bwd_weight(dp2, code2, p1)}
+    for k, fn in fns.items():
+        if only is None or k == only:
+            res[k] = timeit(fn)
     for k, (med, mn) in res.items():
         print(f"{k:20s} B={B} median {med:8.1f} us  min {mn:8.1f} us")
 
