@@ -66,6 +66,7 @@ SIGNATURES = {
     "gdm_cast": (_I, [_P, _I, _P, _I, _L, _P]),
     "gdm_nonfinite_count": (_I, [_P, _I, _L, _P, _P]),
     "gdm_simnn_conv1_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
+    "gdm_simnn_conv1_fwd_pair": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _I, _P]),
     "gdm_simnn_conv2_pack_bytes": (_Z, [_I]),
     "gdm_simnn_conv2_pack": (_I, [_P, _I, _P, _P]),
     "gdm_simnn_conv2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _I, _P]),

@@ -143,7 +143,8 @@ __device__ __forceinline__ void buf_store2(rsrc_t r, uint32_t off, uint32_t v) {
 // stencil this layer cost ~10 instructions per output value and was issue-bound at 40 % of its memory roofline.)
 // =====================================================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                        int bsplit, const float* __restrict__ w,
                                                         const float* __restrict__ bias, int B, int H, int W, int H1,
                                                         int W1, int n_rows, T* __restrict__ p1,
                                                         uint16_t* __restrict__ code1) {
@@ -152,7 +153,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
   // the wave index is uniform: keep everything derived from it in scalar registers
   const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (t >> 6)), n_waves = gridDim.x * 4;
   const int upr = (W1 + 15) >> 4;                            // units per pooled row
-  const rsrc_t xr = make_rsrc(x, (uint32_t)B * H * W * 4);
+  // the batch is the concatenation of two input tensors (images 0 .. bsplit-1 | bsplit .. B-1: real | generated)
+  const rsrc_t xr0 = make_rsrc(x0, (uint32_t)bsplit * H * W * 4);
+  const rsrc_t xr1 = make_rsrc(x1, (uint32_t)(B - bsplit) * H * W * 4);
   const rsrc_t pr = make_rsrc(p1, (uint32_t)B * H1 * W1 * 16 * sizeof(T));
   const rsrc_t cr = make_rsrc(code1, (uint32_t)B * H1 * Q1 * 32);
   // A operand: lane (row = channel lr, k = tap lg); accumulator rows 4lg + r = channels
@@ -169,11 +172,12 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
   // depends on the row (base offsets, row-interior flag, validity) is recomputed only when a slot moves to its next
   // row, behind a scalar branch.  (Per-unit position arithmetic with carries cost ~100 SALU instructions per unit --
   // more than the unit's VALU work; the CU's single scalar unit was the limiter.)
-  struct Slot { int seg, ph, b; uint32_t xrow, pixrow, crow; bool interior, valid; };
+  struct Slot { int seg, ph, b; uint32_t xrow, pixrow, crow; bool interior, valid, second; };
   const int dph = n_waves % H1, db = n_waves / H1;
   auto set_row = [&](Slot& q) {
     const int b = min(q.b, B - 1);                           // past the end: re-read the last image (stores are dropped)
-    q.xrow = (uint32_t)(((b * H + 2 * q.ph) * W) * 4);
+    q.second = b >= bsplit;
+    q.xrow = (uint32_t)((((q.second ? b - bsplit : b) * H + 2 * q.ph) * W) * 4);
     q.pixrow = (uint32_t)((b * H1 + q.ph) * W1);
     q.crow = (uint32_t)(b * H1 + q.ph);
     q.interior = q.ph > 0 && 2 * q.ph + 1 < H;
@@ -189,6 +193,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
   };
   auto load = [&](const Slot& q, float (&xv)[4]) {
+    const rsrc_t xr = q.second ? xr1 : xr0;                  // scalar select
     const uint32_t base = q.xrow + 128u * (uint32_t)q.seg;
     if (q.interior && q.seg > 0 && 32 * q.seg + 32 < W) {    // interior unit (scalar test)
       // the lane's 2x2 patch as two 8-byte loads (4-byte aligned): memory instructions, not bytes, are what the
@@ -1921,10 +1926,11 @@ inline void allow_lds(K kernel, size_t bytes) {
 #define DISPATCH_T(dtype, CALL)                  \
   if ((dtype) == GDM_BF16) { using T = __bf16; CALL; } else { using T = float; CALL; }
 
-extern "C" int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* bias, int B, int H, int W, void* p1,
-                                   uint64_t* code1, int dtype, void* stream) {
-  GDM_REQUIRE(x && w && bias && p1 && code1, "gdm_simnn_conv1_fwd: null pointer");
+extern "C" int gdm_simnn_conv1_fwd_pair(const float* x0, const float* x1, int bsplit, const float* w, const float* bias,
+                                        int B, int H, int W, void* p1, uint64_t* code1, int dtype, void* stream) {
+  GDM_REQUIRE(x0 && w && bias && p1 && code1, "gdm_simnn_conv1_fwd: null pointer");
   GDM_REQUIRE(B > 0 && H >= 1 && W >= 1 && gdm_dtype_ok(dtype), "gdm_simnn_conv1_fwd: bad arguments");
+  GDM_REQUIRE(bsplit >= 1 && bsplit <= B && (bsplit == B || x1 != nullptr), "gdm_simnn_conv1_fwd: second input pointer missing");
   const int H1 = (H + 1) / 2, W1 = (W + 1) / 2;
   GDM_REQUIRE((int64_t)B * H1 * W1 * 64 < ((int64_t)1 << 31) && (int64_t)B * H * W * 4 < ((int64_t)1 << 31),
               "gdm_simnn_conv1_fwd: batch of %d %dx%d inputs exceeds 2 GiB per tensor", B, H, W);
@@ -1932,10 +1938,16 @@ extern "C" int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* 
   int64_t blocks = (n_rows + 3) / 4;                                     // 4 waves per workgroup
   static const int cap1 = tuned_cap("GDM_C1_CAP", 1536);               // persistent: 6 workgroups per CU (2048: +0.6 % per iteration)
   if (blocks > cap1) blocks = cap1;
+  if (bsplit == B) x1 = x0;                                              // never read
   DISPATCH_T(dtype, hipLaunchKernelGGL(conv1_fwd_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                                       x, w, bias, B, H, W, H1, W1, (int)n_rows, (T*)p1, (uint16_t*)code1));
+                                       x0, x1, bsplit, w, bias, B, H, W, H1, W1, (int)n_rows, (T*)p1, (uint16_t*)code1));
   GDM_LAUNCH_OK("gdm_simnn_conv1_fwd");
   return GDM_OK;
+}
+
+extern "C" int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* bias, int B, int H, int W, void* p1,
+                                   uint64_t* code1, int dtype, void* stream) {
+  return gdm_simnn_conv1_fwd_pair(x, nullptr, B, w, bias, B, H, W, p1, code1, dtype, stream);
 }
 
 extern "C" size_t gdm_simnn_conv1_bwd_weight_workspace_bytes(int B, int H, int W) {

@@ -422,12 +422,17 @@ def simnn_code1_width(w1):
     return (w1 + 3) // 4 * 4
 
 
-def simnn_conv1_fwd(x, w, bias, dt, out=None):
+def simnn_conv1_fwd(x, w, bias, dt, out=None, x1=None):
     """out = (p1, code1) preallocated (e.g. halves of a 2B batch buffer) or None; code1: (b, h1, simnn_code1_width(w1))
-    int64 -- an opaque byte image, only ever handed back to the backward entry points."""
-    _need_gpu(x, w, bias)
+    int64 -- an opaque byte image, only ever handed back to the backward entry points.  ``x1``: a second input tensor
+    of the same geometry; the batch is then [x ; x1] in ONE launch (gdm_simnn_conv1_fwd_pair)."""
+    _need_gpu(x, w, bias, x1)
     assert x.dim() == 3 and x.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()
     b, h, wd = x.shape
+    bsplit = b
+    if x1 is not None:
+        assert x1.dtype == torch.float32 and x1.is_contiguous() and x1.shape[1:] == x.shape[1:]
+        b += x1.shape[0]
     h1, w1 = (h + 1) // 2, (wd + 1) // 2
     if out is not None:
         p1, code1 = out
@@ -436,7 +441,7 @@ def simnn_conv1_fwd(x, w, bias, dt, out=None):
     else:
         p1 = torch.empty((b, h1, w1, 16), dtype=_TORCH_DT[dt], device=x.device)
         code1 = torch.empty((b, h1, simnn_code1_width(w1)), dtype=torch.int64, device=x.device)
-    _call("gdm_simnn_conv1_fwd", _p(x), _p(w), _p(bias), b, h, wd, _p(p1), _p(code1), dt, _stream())
+    _call("gdm_simnn_conv1_fwd_pair", _p(x), _p(x1), bsplit, _p(w), _p(bias), b, h, wd, _p(p1), _p(code1), dt, _stream())
     return p1, code1
 
 

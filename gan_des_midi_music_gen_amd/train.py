@@ -14,6 +14,8 @@ MMGAN_MIDI_DES/network_tests.py:281-321), restructured for MI355X:
 Generators are never updated by the reference loops (no gradient crosses the DES bridge); only their BatchNorm
 running statistics move, once (model 1) or twice (model 2) per iteration.
 """
+import os
+
 import torch
 
 from . import dp
@@ -414,13 +416,12 @@ class SimnnTrainer(_TrainerBase):
         adt = ops.torch_dtype(dt)
         p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=real.device)
         code1 = torch.empty((2 * b, h1, ops.simnn_code1_width(w1s)), dtype=torch.int64, device=real.device)
-        ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
+        ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1, code1), x1=fake)        # [real ; fake] in one launch
         if not bridge:
             # tensor stand-in for the bridge: the generator is independent of the discriminator step and runs beside
             # it.  Forked after the first main-stream launch: a branch that forks at the very root of a captured graph
             # was observed to run BEFORE the main branch instead of beside it.
             generator_forward()
-        ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
         hid, saved = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1, code1))
         # fc2 + sigmoid + both BCE terms (labels 0.9 / 0.1, SIMNN.py:284-311) + head backward: one launch pair
         _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 0.9, 0.1, loss_out=self.loss_d, grad_out=(gv[6], gv[7], gv[5]),
@@ -495,7 +496,7 @@ class SimnnTrainer(_TrainerBase):
         adt = ops.torch_dtype(dt)
         p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=real.device)
         code1 = torch.empty((2 * b, h1, ops.simnn_code1_width(w1s)), dtype=torch.int64, device=real.device)
-        ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
+        ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1, code1), x1=fake)        # [real ; fake] in one launch
         # branches fork after the first main-stream launch (see step)
         if with_generator:
             if side:
@@ -505,7 +506,6 @@ class SimnnTrainer(_TrainerBase):
                                                                need_backward=False)
                 keep.append(gsaved)
             self._last_generated = generated
-        ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
         # generator half of the previous iteration: reads the weights / prepared operands that stay untouched until
         # this call's Adam, writes only gen_loss and scratch buffers.  Then, on the same stream (so after the half's last
         # read of it), the trainer's own copy of the fake batch is refreshed with THIS iteration's: the caller may
@@ -638,8 +638,7 @@ class SimnnTrainer(_TrainerBase):
         with cap("a"), torch.cuda.graph(g["a"]):
             p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=dev)
             code1 = torch.empty((2 * b, h1, ops.simnn_code1_width(w1s)), dtype=torch.int64, device=dev)
-            ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
-            ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
+            ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1, code1), x1=fake)
             hid, saved = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1, code1))
             _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 0.9, 0.1, loss_out=self.loss_d, grad_out=(gv[6], gv[7], gv[5]),
                                           dh_dtype=dt)

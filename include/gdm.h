@@ -168,6 +168,10 @@ int gdm_nonfinite_count(const void* x, int dtype, int64_t n, int* counter, void*
  * operand layouts, in `dtype`); rebuild it whenever the weights change.                                            */
 int gdm_simnn_conv1_fwd(const float* x, const float* w, const float* bias, int B, int H, int W, void* p1,
                         uint64_t* code1, int dtype, void* stream);
+/* the same for a batch that is the concatenation of two input tensors, images 0 .. bsplit-1 from x0 and bsplit .. B-1
+ * from x1 (the discriminator step's [real ; generated] batch, SIMNN.py:306-310, in one launch, without a torch.cat) */
+int gdm_simnn_conv1_fwd_pair(const float* x0, const float* x1, int bsplit, const float* w, const float* bias, int B,
+                             int H, int W, void* p1, uint64_t* code1, int dtype, void* stream);
 size_t gdm_simnn_conv2_pack_bytes(int dtype);
 int gdm_simnn_conv2_pack(const float* w, int dtype, void* pack, void* stream);
 int gdm_simnn_conv2_fwd(const void* p1, const void* pack, const float* bias, int B, int H1, int W1, void* p2,

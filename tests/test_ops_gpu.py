@@ -378,3 +378,20 @@ def test_permute_pc():
 def test_cpu_tensor_is_rejected():
     with pytest.raises(ops.GdmError):
         ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_conv1_forward_of_a_two_tensor_batch_in_one_launch(dt):
+    """gdm_simnn_conv1_fwd_pair: the batch [x0 ; x1] (different sizes) in ONE launch equals the two launches bit for bit."""
+    dtc = ops.BF16 if dt == "bf16" else ops.F32
+    g = torch.Generator().manual_seed(5)
+    x0 = (torch.randn(3, 30, 44, generator=g) * 18 - 35).to(DEV)
+    x1 = (torch.randn(5, 30, 44, generator=g) * 18 - 35).to(DEV)
+    w = (torch.randn(16, 1, 2, 2, generator=g) * 0.2).to(DEV)
+    bias = (torch.randn(16, generator=g) * 0.5 + 2.0).to(DEV)
+    pa, ca = ops.simnn_conv1_fwd(x0, w, bias, dtc)
+    pb, cb = ops.simnn_conv1_fwd(x1, w, bias, dtc)
+    p, c = ops.simnn_conv1_fwd(x0, w, bias, dtc, x1=x1)
+    assert p.shape[0] == 8
+    assert torch.equal(p[:3], pa) and torch.equal(p[3:], pb)
+    assert torch.equal(c[:3], ca) and torch.equal(c[3:], cb)
