@@ -14,8 +14,6 @@ MMGAN_MIDI_DES/network_tests.py:281-321), restructured for MI355X:
 Generators are never updated by the reference loops (no gradient crosses the DES bridge); only their BatchNorm
 running statistics move, once (model 1) or twice (model 2) per iteration.
 """
-import os
-
 import torch
 
 from . import dp
