@@ -1,0 +1,6 @@
+set -x
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 900 python -m pytest tests/test_simnn_gpu.py tests/test_ops_gpu.py tests/test_trainer_parity_bf16_gpu.py -m gpu -x -q > gpurun_out/r3_t29.log 2>&1; rc=$?; tail -5 gpurun_out/r3_t29.log; [ $rc -eq 0 ] || exit $rc
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_simnn_eager -- python bench.py --steps 10 --warmup 3 --prime 0 --no-cpu-baseline --no-secondary --no-graph --no-overlap > gpurun_out/final_simnn_eager.log 2>&1
+python tools/trace_split.py gpurun_out/final_simnn_eager 4
+python bench.py --no-cpu-baseline --no-secondary --no-roofline | cut -c1-200
