@@ -168,13 +168,15 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
   for (int p = 0; p < 4; ++p) loff[p] = (uint32_t)(((r_lo + (p >> 1)) * W + c_lo + (p & 1)) * 4);   // may wrap: added to base
 
   // Work is dealt by pooled ROW: wave w takes rows w, w + n_waves, ... of the (b, ph) row space and walks each row's
-  // units left to right, so the per-unit bookkeeping is "seg += DEPTH, compare" in scalar registers; everything that
-  // depends on the row (base offsets, row-interior flag, validity) is recomputed only when a slot moves to its next
-  // row, behind a scalar branch.  (Per-unit position arithmetic with carries cost ~100 SALU instructions per unit --
-  // more than the unit's VALU work; the CU's single scalar unit was the limiter.)
-  struct Slot { int seg, ph, b; uint32_t xrow, pixrow, crow; bool interior, valid, second; };
+  // units left to right in CHUNKS of DEPTH units that share one row record: everything that depends on the row (base
+  // offsets, row-interior flag, validity) is computed once per row, behind a scalar branch, and a unit costs a handful
+  // of scalar instructions.  The CU's ONE scalar unit is what this kernel queues for: with per-unit position
+  // arithmetic with carries (~100 SALU per unit) it was slower than its VALU work; with four independently advancing
+  // slots (~45 SALU per unit, a row change every other step of each slot) a phase-stamp build still showed 36 % of a
+  // wave's time in "bookkeeping + next loads" (`tools/stamps.py c1`).
+  struct Row { int ph, b; uint32_t xrow, pixrow, crow; bool interior, valid, second; };
   const int dph = n_waves % H1, db = n_waves / H1;
-  auto set_row = [&](Slot& q) {
+  auto set_row = [&](Row& q) {
     const int b = min(q.b, B - 1);                           // past the end: re-read the last image (stores are dropped)
     q.second = b >= bsplit;
     q.xrow = (uint32_t)((((q.second ? b - bsplit : b) * H + 2 * q.ph) * W) * 4);
@@ -183,19 +185,10 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     q.interior = q.ph > 0 && 2 * q.ph + 1 < H;
     q.valid = q.b < B;
   };
-  auto step = [&](Slot& q, int n) {
-    q.seg += n;
-    while (q.seg >= upr) {
-      q.seg -= upr;
-      q.ph += dph; q.b += db;
-      if (q.ph >= H1) { q.ph -= H1; ++q.b; }
-      set_row(q);
-    }
-  };
-  auto load = [&](const Slot& q, float (&xv)[4]) {
+  auto load = [&](const Row& q, int seg, float (&xv)[4]) {
     const rsrc_t xr = q.second ? xr1 : xr0;                  // scalar select
-    const uint32_t base = q.xrow + 128u * (uint32_t)q.seg;
-    if (q.interior && q.seg > 0 && 32 * q.seg + 32 < W) {    // interior unit (scalar test)
+    const uint32_t base = q.xrow + 128u * (uint32_t)seg;
+    if (q.interior && seg > 0 && 32 * seg + 32 < W) {        // interior unit (scalar test)
       // the lane's 2x2 patch as two 8-byte loads (4-byte aligned): memory instructions, not bytes, are what the
       // address unit charges for
 #pragma unroll
@@ -206,13 +199,14 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       }
       return;
     }
-    const int row0 = 2 * q.ph + r_lo, col0 = 32 * q.seg + c_lo;
+    // edge unit (also: a unit past the end of its row, seg >= upr -- its stores are dropped)
+    const int row0 = 2 * q.ph + r_lo, col0 = 32 * seg + c_lo;
     const bool rok[2] = {(unsigned)row0 < (unsigned)H, (unsigned)(row0 + 1) < (unsigned)H};
     const bool cok[2] = {(unsigned)col0 < (unsigned)W, (unsigned)(col0 + 1) < (unsigned)W};
 #pragma unroll
     for (int p = 0; p < 4; ++p) xv[p] = buf_load4<GDM_IN_LOAD_AUX>(xr, (rok[p >> 1] && cok[p & 1]) ? base + loff[p] : BUF_OOB);
   };
-  auto finish = [&](const Slot& q, const float (&xv)[4]) {
+  auto finish = [&](const Row& q, int seg, const float (&xv)[4]) {
     f32x4 acc[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, xv[p], b4, 0, 0, 0);
@@ -229,7 +223,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       best[r] = fmaxf(m, 0.f);
       field |= (m > 0.f ? pos | 4u : pos) << (4 * r);
     }
-    const int pw = 16 * q.seg + lr;
+    const int pw = 16 * seg + lr;
     const uint32_t pix = q.pixrow + (uint32_t)pw;
     const bool ok = q.valid && pw < W1;
     if constexpr (sizeof(T) == 2) {
@@ -245,29 +239,39 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
                                    ok ? field : 0u);
   };
   if (wave >= n_rows) return;
-  // DEPTH units in flight per wave; every trip issues the same loads and stores (units past the end re-read valid
-  // memory and their stores are dropped), so the waits between them are exact counts.  The sched_barriers keep the
-  // compiler from sinking the refill loads below the next unit's MFMAs (which would expose their latency again).
+  // DEPTH units in flight per wave: while the units of this chunk are finished, the loads of the next chunk (same row
+  // or the wave's next row) are issued into the registers they free.  Every trip issues the same loads and stores
+  // (units past the end of a row or of the batch read valid memory and their stores are dropped), so the waits between
+  // them are exact counts.  The sched_barriers keep the compiler from sinking the refill loads below the next unit's
+  // MFMAs (which would expose their latency again).
 #ifndef GDM_C1_DEPTH
 #define GDM_C1_DEPTH 4
 #endif
   constexpr int DEPTH = GDM_C1_DEPTH;
-  Slot q[DEPTH];
+  Row rc;
   float xv[DEPTH][4];
-  q[0].seg = 0; q[0].ph = wave % H1; q[0].b = wave / H1;
-  set_row(q[0]);
+  rc.ph = wave % H1; rc.b = wave / H1;
+  set_row(rc);
+  int seg0 = 0;
 #pragma unroll
-  for (int d = 1; d < DEPTH; ++d) { q[d] = q[d - 1]; step(q[d], 1); }
-#pragma unroll
-  for (int d = 0; d < DEPTH; ++d) load(q[d], xv[d]);
-  while (q[0].valid) {                          // slot 0 is the earliest unit of the trip
+  for (int d = 0; d < DEPTH; ++d) load(rc, d, xv[d]);
+  while (rc.valid) {
+    Row rn = rc;
+    int seg0n = seg0 + DEPTH;
+    if (seg0n >= upr) {                         // the wave's next row
+      seg0n = 0;
+      rn.ph += dph; rn.b += db;
+      if (rn.ph >= H1) { rn.ph -= H1; ++rn.b; }
+      set_row(rn);
+    }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-      finish(q[d], xv[d]);
-      step(q[d], DEPTH);
-      load(q[d], xv[d]);
+      finish(rc, seg0 + d, xv[d]);
+      load(rn, seg0n + d, xv[d]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    rc = rn;
+    seg0 = seg0n;
   }
 }
 
