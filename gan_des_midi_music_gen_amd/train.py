@@ -414,7 +414,10 @@ class SimnnTrainer(_TrainerBase):
         adt = ops.torch_dtype(dt)
         p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=real.device)
         code1 = torch.empty((2 * b, h1, ops.simnn_code1_width(w1s)), dtype=torch.int64, device=real.device)
-        ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1, code1), x1=fake)        # [real ; fake] in one launch
+        # two B launches, not one 2B launch (ops.simnn_conv1_fwd(..., x1=fake)): inside the iteration the 2B launch takes
+        # 64-66 us against 2 x 28 (same-box A/B of the step: 0.612-0.614 vs 0.608-0.610 ms)
+        ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
+        ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
         if not bridge:
             # tensor stand-in for the bridge: the generator is independent of the discriminator step and runs beside
             # it.  Forked after the first main-stream launch: a branch that forks at the very root of a captured graph
@@ -494,7 +497,10 @@ class SimnnTrainer(_TrainerBase):
         adt = ops.torch_dtype(dt)
         p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=real.device)
         code1 = torch.empty((2 * b, h1, ops.simnn_code1_width(w1s)), dtype=torch.int64, device=real.device)
-        ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1, code1), x1=fake)        # [real ; fake] in one launch
+        # two B launches, not one 2B launch (ops.simnn_conv1_fwd(..., x1=fake)): inside the iteration the 2B launch takes
+        # 64-66 us against 2 x 28 (same-box A/B of the step: 0.612-0.614 vs 0.608-0.610 ms)
+        ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
+        ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
         # branches fork after the first main-stream launch (see step)
         if with_generator:
             if side:
@@ -636,7 +642,8 @@ class SimnnTrainer(_TrainerBase):
         with cap("a"), torch.cuda.graph(g["a"]):
             p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=dev)
             code1 = torch.empty((2 * b, h1, ops.simnn_code1_width(w1s)), dtype=torch.int64, device=dev)
-            ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1, code1), x1=fake)
+            ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
+            ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
             hid, saved = Fn.simnn_disc_features(None, w1, b1, pack, b2, wf1p, bf1, dt, trunk_out=(p1, code1))
             _prob, dh, _ = ops.simnn_head(hid, wf2, bf2, b, 0.9, 0.1, loss_out=self.loss_d, grad_out=(gv[6], gv[7], gv[5]),
                                           dh_dtype=dt)
