@@ -84,9 +84,14 @@ __global__ __launch_bounds__(256 * GP) void linear_bn_act_kernel(LbJobs jobs, fl
   // together and one k-tile ahead of the MFMAs (register prefetch): these layers are latency-bound, not bandwidth-bound.
   // VEC (chosen on the host): K % 4 == 0 and 16-byte aligned operands -> every chunk is inside or outside the row as a whole
   f32x4 ra[8], rb;
+  // Small batches (the reference trains model 2 with 16 rows): staging pass i covers rows [32 i, 32 i + 32) and
+  // accumulator tile (wave, i) rows [64 wv + 16 i, + 16) -- passes and tiles that hold no row of the batch are skipped
+  // (wave-uniform tests), so a k-tile of a 16-row batch costs one staging pass and 6 MFMAs in one wave instead of eight
+  // passes and 24 MFMAs in each of the four.
   auto load_tile = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+      if (32 * i >= M) continue;
       const int idx = t + 256 * i, m = idx >> 3, k = k0 + (idx & 7) * 4;
       ra[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (m < M) {
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(256 * GP) void linear_bn_act_kernel(LbJobs jobs, fl
     __syncthreads();                       // the previous tile's fragment reads are done
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+      if (32 * i >= M) continue;
       const int idx = t + 256 * i;
       bf16x4 h, lo;
 #pragma unroll
@@ -141,6 +147,7 @@ __global__ __launch_bounds__(256 * GP) void linear_bn_act_kernel(LbJobs jobs, fl
       for (int h = 0; h < 2; ++h) b[h][j] = *(const bf16x8*)&Bs[h][(16 * j + lr) * LB_LD + 8 * lg];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if (64 * wv + 16 * i >= M) continue;           // no row of the batch in this tile: its accumulators stay zero
       const bf16x8 ah = *(const bf16x8*)&As[0][(64 * wv + 16 * i + lr) * LB_LD + 8 * lg];
       const bf16x8 al = *(const bf16x8*)&As[1][(64 * wv + 16 * i + lr) * LB_LD + 8 * lg];
 #pragma unroll
