@@ -415,7 +415,7 @@ class SimnnTrainer(_TrainerBase):
         p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=real.device)
         code1 = torch.empty((2 * b, h1, ops.simnn_code1_width(w1s)), dtype=torch.int64, device=real.device)
         # two B launches, not one 2B launch (ops.simnn_conv1_fwd(..., x1=fake)): inside the iteration the 2B launch takes
-        # 64-66 us against 2 x 28 (same-box A/B of the step: 0.612-0.614 vs 0.608-0.610 ms)
+        # 64-66 us against 2 x 30 (same-box A/B of the step: 0.612-0.614 vs 0.608-0.610 ms)
         ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
         ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
         if not bridge:
@@ -498,7 +498,7 @@ class SimnnTrainer(_TrainerBase):
         p1 = torch.empty((2 * b, h1, w1s, 16), dtype=adt, device=real.device)
         code1 = torch.empty((2 * b, h1, ops.simnn_code1_width(w1s)), dtype=torch.int64, device=real.device)
         # two B launches, not one 2B launch (ops.simnn_conv1_fwd(..., x1=fake)): inside the iteration the 2B launch takes
-        # 64-66 us against 2 x 28 (same-box A/B of the step: 0.612-0.614 vs 0.608-0.610 ms)
+        # 64-66 us against 2 x 30 (same-box A/B of the step: 0.612-0.614 vs 0.608-0.610 ms)
         ops.simnn_conv1_fwd(real, w1, b1, dt, out=(p1[:b], code1[:b]))
         ops.simnn_conv1_fwd(fake, w1, b1, dt, out=(p1[b:], code1[b:]))
         # branches fork after the first main-stream launch (see step)
