@@ -13,9 +13,13 @@ This file restates their published algorithm with the defaults the reference cal
   * AmplitudeToDB(stype="power", top_db): 10 log10(clamp(x, 1e-10)) (reference value 1.0), then every value is raised to
     at least (max over the spectrogram) - top_db.
 
-PARITY UNPINNED: torchaudio cannot be imported here (no wheel, no network) and the reference holds no numeric fixture
-for this function, so nothing ties this restatement to torchaudio's bits; it is checked against analytic properties
-(tests/test_mel.py: filter-bank partition, a pure tone lands in the right band at the right level, Parseval).
+PARITY PINNED TO IMPORTABLE RE-IMPLEMENTATIONS, NOT TO TORCHAUDIO ITSELF: torchaudio cannot be imported here (no wheel,
+no network) and the reference holds no numeric fixture for this function.  Every stage is tied to an independent,
+importable implementation of the same published algorithm (tests/test_mel.py): the STFT to ``torch.stft`` -- the very
+function torchaudio's Spectrogram calls -- (1e-12 in float64), the filter bank to
+``transformers.audio_utils.mel_filter_bank(norm=None, mel_scale="htk")`` (identical), the dB conversion to its
+``power_to_db`` (float32 rounding), and the whole pipeline to the three chained.  What stays unverified is that
+torchaudio 2.2.1's own code equals that published algorithm bit for bit.
 numpy float64 FFT internally, float32 result.
 """
 import numpy as np

@@ -1,8 +1,13 @@
 """Mel-spectrogram featuriser (first "next" row; reference GAN_DES/util.py:37-61).
 
-PARITY UNPINNED: torchaudio (where the reference's arithmetic lives) is not importable here and the reference ships no
-numeric fixture for this function.  The CPU tests pin the oracle restatement (oracle/mel.py) to analytic properties of
-the published algorithm; the GPU tests compare the HIP path with that oracle on seeded signals.
+PARITY PARTLY PINNED: torchaudio (where the reference's arithmetic lives) is not importable here and the reference
+ships no numeric fixture for this function.  Its first and heaviest stage is pinned all the same: torchaudio's
+``Spectrogram`` IS ``torch.stft(...).abs().pow(2)`` with a periodic Hann window, and torch.stft is importable -- the
+oracle's STFT is compared with it at the reference's geometry (test_oracle_stft_is_torch_stft).  The mel filter bank and
+the dB conversion are compared with transformers.audio_utils (an importable, independent implementation documented as
+torchaudio-compatible), and so is the whole pipeline assembled from the two libraries
+(test_oracle_filter_bank_and_db_are_the_published_ones); torchaudio's own bits remain out of reach.  The GPU tests compare
+the HIP path with the oracle on seeded signals.
 """
 import numpy as np
 import pytest
@@ -39,6 +44,55 @@ def test_oracle_filter_bank_and_shapes():
     out = om.get_melspectrogram_db_tensor(_window(0))
     assert out.shape == (128, 216) and out.dtype == np.float32          # the discriminator's (128, 216) input
     assert out.max() - out.min() <= 80.0 + 1e-4                          # top_db floor
+
+
+@pytest.mark.parametrize("n", [5 * SR, 3 * SR + 123, 4410])
+def test_oracle_stft_is_torch_stft(n):
+    """torchaudio.transforms.Spectrogram(n_fft=2048, hop_length=hop, power=2) is
+    ``torch.stft(x, 2048, hop, 2048, hann_window(2048) [periodic], center=True, pad_mode="reflect", normalized=False,
+    onesided=True, return_complex=True).abs().pow(2)`` (torchaudio/functional/functional.py: spectrogram): the stage of
+    the featuriser that an importable library pins.  float64 against the oracle's float64 FFT, and torch's float32
+    result (what the reference computes in) within float32 rounding of it."""
+    x = _window(7, n)
+    hop = n // 215                                                        # util.py:43
+    want = om.stft_power(x, 2048, hop)
+    xt = torch.from_numpy(x)
+    for dt, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
+        w = torch.hann_window(2048, periodic=True, dtype=dt)
+        got = torch.stft(xt.to(dt), n_fft=2048, hop_length=hop, win_length=2048, window=w, center=True,
+                         pad_mode="reflect", normalized=False, onesided=True, return_complex=True).abs().pow(2)
+        assert tuple(got.shape) == want.shape == (1025, 1 + n // hop)
+        err = np.abs(got.numpy().astype(np.float64) - want).max() / want.max()
+        assert err < tol, (dt, err)
+    np.testing.assert_allclose(om.hann_periodic(2048), torch.hann_window(2048, periodic=True, dtype=torch.float64).numpy(),
+                               atol=1e-15)
+
+
+def test_oracle_filter_bank_and_db_are_the_published_ones():
+    """The other two stages against an importable independent implementation of the same published algorithm:
+    ``transformers.audio_utils.mel_filter_bank(norm=None, mel_scale="htk")`` (documented as torchaudio's
+    ``melscale_fbanks``) and ``power_to_db(reference=1, min_value=1e-10, db_range=top_db)`` (= AmplitudeToDB("power",
+    top_db)).  Then the whole featuriser, stage by stage from those libraries, against the oracle."""
+    au = pytest.importorskip("transformers.audio_utils")
+    fb = om.melscale_fbanks(1025, 20.0, 8300.0, 128, SR)
+    ref_fb = au.mel_filter_bank(num_frequency_bins=1025, num_mel_filters=128, min_frequency=20.0, max_frequency=8300.0,
+                                sampling_rate=SR, norm=None, mel_scale="htk")
+    np.testing.assert_allclose(fb, ref_fb, rtol=0, atol=1e-12)
+    g = np.random.default_rng(3)
+    pw = (np.abs(g.standard_normal((128, 216))) ** 2 * 10.0).astype(np.float32)
+    pw[5, 7] = 0.0                                                         # the 1e-10 clamp
+    np.testing.assert_allclose(om.amplitude_to_db(pw, 80.0),
+                               au.power_to_db(pw.astype(np.float64), reference=1.0, min_value=1e-10, db_range=80.0),
+                               atol=2e-5)
+    x = _window(11)
+    hop = len(x) // 215
+    w = torch.hann_window(2048, periodic=True, dtype=torch.float64)
+    power = torch.stft(torch.from_numpy(x).double(), n_fft=2048, hop_length=hop, win_length=2048, window=w, center=True,
+                       pad_mode="reflect", normalized=False, onesided=True, return_complex=True).abs().pow(2).numpy()
+    want = au.power_to_db(ref_fb.T @ power, reference=1.0, min_value=1e-10, db_range=80.0)[:, :216]
+    got = om.get_melspectrogram_db_tensor(x)
+    assert got.shape == (128, 216)
+    np.testing.assert_allclose(got, want, atol=1e-3)                      # dB; float32 result
 
 
 def test_oracle_pure_tone_level_and_parseval():
