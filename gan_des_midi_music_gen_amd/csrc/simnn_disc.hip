@@ -206,10 +206,19 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
     for (int p = 0; p < 4; ++p) xv[p] = buf_load4<GDM_IN_LOAD_AUX>(xr, (rok[p >> 1] && cok[p & 1]) ? base + loff[p] : BUF_OOB);
   };
+  STAMP_DECL;
   auto finish = [&](const Row& q, int seg, const float (&xv)[4]) {
     f32x4 acc[4];
+#ifdef GDM_STAMPS
+    asm volatile("" :: "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]));      // the unit's loads have landed
+    STAMP(0);
+#endif
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, xv[p], b4, 0, 0, 0);
+#ifdef GDM_STAMPS
+    asm volatile("" :: "v"(acc[3][3]));                                        // the MFMAs have finished
+    STAMP(1);
+#endif
     uint32_t field = 0;
     float best[4];
 #pragma unroll
@@ -226,6 +235,10 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     const int pw = 16 * seg + lr;
     const uint32_t pix = q.pixrow + (uint32_t)pw;
     const bool ok = q.valid && pw < W1;
+#ifdef GDM_STAMPS
+    asm volatile("" :: "v"(field), "v"(best[0]), "v"(best[3]));
+    STAMP(2);
+#endif
     if constexpr (sizeof(T) == 2) {
       bf16x4 h;
 #pragma unroll
@@ -237,6 +250,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     // the whole last quad is written (zeros beyond W1): its consumers load four pixels' fields at once
     buf_store2<GDM_ACT_STORE_AUX2>(cr, (q.valid && pw < 4 * Q1) ? code1_field(q.crow, Q1, pw, lg) * 2u : BUF_OOB,
                                    ok ? field : 0u);
+    STAMP(3);
   };
   if (wave >= n_rows) return;
   // DEPTH units in flight per wave: while the units of this chunk are finished, the loads of the next chunk (same row
@@ -268,11 +282,13 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     for (int d = 0; d < DEPTH; ++d) {
       finish(rc, seg0 + d, xv[d]);
       load(rn, seg0n + d, xv[d]);
+      STAMP(4);
       __builtin_amdgcn_sched_barrier(0);
     }
     rc = rn;
     seg0 = seg0n;
   }
+  STAMP_FLUSH;
 }
 
 // =====================================================================================================================

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: where does a persistent conv2 kernel's tile loop spend its cycles?
+"""Diagnostic: where does a persistent conv kernel's loop (conv2: fwd / bwd / bww, conv1 forward: c1) spend its cycles?
 
 Build the library with -DGDM_STAMPS (GDM_HIPCC_FLAGS=-DGDM_STAMPS python -m gan_des_midi_music_gen_amd.build, then
 restore the normal build), run this on the GPU box: it launches the kernel once and prints the mean per-workgroup
@@ -34,10 +34,12 @@ def main():
     dp2 = torch.randn_like(p2.float()).to(torch.bfloat16)
     names = {"fwd": ["store->barrier", "issue", "mfma", "epilogue", "end barrier", "prologue", "wait+ds_write", "-"],
              "bwd": ["barrier after expand", "issue (loads 2 steps ahead)", "data-gradient mfma", "loop bookkeeping", "conv1-dW epilogue", "end barrier", "prologue + WAIT FOR THIS STEP'S LOADS", "expand + x planes"],
-             "bww": ["barrier", "issue", "mfma", "end barrier", "prologue", "wait for loads", "expand + p1 store", "-"]}[which]
+             "bww": ["barrier", "issue", "mfma", "end barrier", "prologue", "wait for loads", "expand + p1 store", "-"],
+             "c1": ["wait for the unit's loads", "4 MFMAs until the result is there", "pool / argmax / ReLU (VALU)", "address + 2 stores", "bookkeeping + next loads", "-", "-", "-"]}[which]
     fn = {"fwd": lambda: ops.simnn_conv2_fwd(p1, pack, b2),
           "bwd": lambda: ops.simnn_conv2_bwd_fused(dp2, code2, pack, code1, x),
-          "bww": lambda: ops.simnn_conv2_bwd_weight(dp2, code2, p1)}[which]
+          "bww": lambda: ops.simnn_conv2_bwd_weight(dp2, code2, p1),
+          "c1": lambda: ops.simnn_conv1_fwd(x, w1, b1, BF16)}[which]
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
