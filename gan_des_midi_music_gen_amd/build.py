@@ -22,6 +22,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
          # no NaN handling in the arithmetic: without it every MFMA result that reaches an fmaxf is first
          # canonicalised (v_max_f32 x, x, x) -- 16 extra VALU per 16 pooled pixels in the issue-bound conv epilogues
          "-fno-honor-nans"]
+# per-source additions to FLAGS (experiments: GDM_HIPCC_FILE_FLAGS="gemm_bf16.hip:-mllvm,-amdgpu-sched-strategy=max-ilp")
+PER_FILE_FLAGS = {}
+for _spec in os.environ.get("GDM_HIPCC_FILE_FLAGS", "").split():
+    _name, _, _fl = _spec.partition(":")
+    PER_FILE_FLAGS[_name] = _fl.split(",")
 EXPERIMENT = os.environ.get("GDM_HIPCC_FLAGS", "").split()     # experiment switches (-D...), empty for the shipped build
 if EXPERIMENT:
     # an instrumented / variant build says so: gdm_build_flavor() returns 1 and bench.py refuses to measure it
@@ -49,7 +54,7 @@ def _flags_stamp(hipcc):
         ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip()
     except OSError:
         ver = "?"
-    return " ".join(FLAGS) + "\n" + ver + "\n"
+    return " ".join(FLAGS) + "\n" + repr(sorted(PER_FILE_FLAGS.items())) + "\n" + ver + "\n"
 
 
 def build(force=False, verbose=False):
@@ -72,7 +77,7 @@ def build(force=False, verbose=False):
 
     def cc(job):
         s, o = job
-        cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+        cmd = [hipcc, *FLAGS, *PER_FILE_FLAGS.get(os.path.basename(s), []), "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return s, r.returncode, r.stdout + r.stderr
 
